@@ -1,0 +1,67 @@
+"""Shared test helpers: golden loading and tolerance checks."""
+import glob
+import os
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# north_star tolerance: 1e-5 relative fp32 on activations / logits.  Relative to
+# the max-norm of the reference tensor (element-wise relative error is not
+# meaningful for entries that cancel to ~0).
+RTOL = 1e-5
+
+
+def golden_cases(prefix=""):
+    files = sorted(glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
+    return [os.path.basename(f)[:-4] for f in files if not os.path.basename(f).startswith("state_")]
+
+
+def load_case(name):
+    d = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    L, m, f0, H, C, le, B, n = [int(x) for x in d["cfg"]]
+    cfg = dict(L=L, m=m, f0=f0, H=H, C=C, learn_eps=bool(le), B=B, n=n,
+               gpool=str(d["gpool"]), npool=str(d["npool"]), row_stride=int(d["row_stride"]),
+               np_seed=int(d["np_seed"]))
+    state = dict(np.load(os.path.join(GOLDEN_DIR, str(d["state_file"]))))
+    return cfg, state, d
+
+
+def edge_mat_of(und):
+    """util.py:99-103: all (i,j) pairs then all (j,i) pairs, as a [2,E] int64."""
+    e = np.asarray(und, dtype=np.int64).reshape(-1, 2)
+    return np.ascontiguousarray(np.concatenate([e, e[:, ::-1]], 0).T)
+
+
+def rel_err(a, ref, floor=0.0):
+    """max|a-ref| / max(max|ref|, floor).  `floor` is an absolute scale for
+    quantities that are analytically zero (e.g. the bias gradient of a Linear
+    that feeds a train-mode BatchNorm), where both sides are rounding noise."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    if ref.size == 0:
+        return 0.0
+    nan_a, nan_r = np.isnan(a), np.isnan(ref)
+    assert np.array_equal(nan_a, nan_r), "NaN pattern differs"
+    scale = np.max(np.abs(ref[~nan_r])) if (~nan_r).any() else 0.0
+    scale = max(scale, floor)
+    if scale == 0.0:
+        return float(np.max(np.abs(a[~nan_a]))) if (~nan_a).any() else 0.0
+    return float(np.max(np.abs(a[~nan_a] - ref[~nan_r])) / scale)
+
+
+def grad_floor(d):
+    """2e-2 x the largest gradient entry of the golden case: the scale below
+    which a gradient tensor is treated as 'analytically zero'."""
+    m = 0.0
+    for k in d:
+        if k.startswith("grad_") and d[k].size:
+            m = max(m, float(np.max(np.abs(d[k]))))
+    return 2e-2 * m
+
+
+def assert_close(a, ref, rtol=RTOL, what="", floor=0.0):
+    e = rel_err(a, ref, floor)
+    assert e <= rtol, f"{what}: rel err {e:.3e} > {rtol:.1e}"
+    return e
