@@ -11,6 +11,15 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # meaningful for entries that cancel to ~0).
 RTOL = 1e-5
 
+# True-shape (n=400, mean degree 119, 5 layers) per-node activations: measured in
+# this container, the REFERENCE's own fp32 result sits up to 2.2e-5 (hidden layer
+# 4) from the fp64 oracle -- fp32 rounding amplified by depth, not an
+# implementation difference.  No fp32 implementation can be pinned tighter than
+# that to another fp32 implementation, so deep true-shape activations are
+# checked against the fp64 oracle with the bound
+#     max(RTOL, TRUE_SHAPE_FACTOR * err(reference golden, fp64 oracle)).
+TRUE_SHAPE_FACTOR = 4.0
+
 
 def golden_cases(prefix=""):
     files = sorted(glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
@@ -65,3 +74,22 @@ def assert_close(a, ref, rtol=RTOL, what="", floor=0.0):
     e = rel_err(a, ref, floor)
     assert e <= rtol, f"{what}: rel err {e:.3e} > {rtol:.1e}"
     return e
+
+
+class Calibrated:
+    """Calibrated comparison for the true-shape case (see TRUE_SHAPE_FACTOR).
+    Keeps the running maximum of the reference's own error vs the fp64 oracle
+    along the layer sequence, because a tensor inherits the noise of its inputs."""
+
+    def __init__(self, base_rtol=RTOL):
+        self.base = base_rtol
+        self.noise = 0.0
+
+    def check(self, a, golden, truth64, what="", floor=0.0):
+        ref_noise = rel_err(golden, truth64, floor)
+        assert ref_noise <= 1e-3, f"{what}: reference golden is {ref_noise:.2e} from the fp64 oracle"
+        self.noise = max(self.noise, ref_noise)
+        bound = max(self.base, TRUE_SHAPE_FACTOR * self.noise)
+        e = rel_err(a, truth64, floor)
+        assert e <= bound, f"{what}: err vs fp64 oracle {e:.3e} > {bound:.2e} (reference noise {self.noise:.2e})"
+        return e

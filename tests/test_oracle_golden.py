@@ -7,7 +7,8 @@ float32 outputs (it is the build's only fp64 cross-check)."""
 import numpy as np
 import pytest
 
-from helpers import RTOL, assert_close, edge_mat_of, golden_cases, grad_floor, load_case
+from helpers import (RTOL, Calibrated, assert_close, edge_mat_of, golden_cases, grad_floor,
+                     load_case)
 from oracle import gin_oracle as O
 
 CASES = golden_cases()
@@ -69,12 +70,29 @@ def test_train_step(case, dtype):
     out = model.train_step_grads(batch, d["perm"], beta=0.05)
     rs = slice(None, None, cfg["row_stride"])
     cache = out["cache"]
-    for l in range(cfg["L"]):
-        assert_close(cache["layers"][l]["pooled"][rs], d[f"train_pooled_{l}"], what=f"pooled {l}")
-        assert_close(cache["hidden"][l][rs], d[f"train_hidden_{l}"], what=f"hidden {l}")
-    assert_close(out["c_logit"], d["train_c_logit"], what="c_logit")
-    assert_close(out["d_logit"], d["train_d_logit"], what="d_logit")
-    assert_close(np.array([out["loss"], out["c_loss"], out["d_loss"]]), d["train_loss"], what="loss")
+    if case.startswith("true_"):
+        # deep true-shape activations: calibrated against the fp64 oracle (helpers.TRUE_SHAPE_FACTOR)
+        truth_out = make_model(cfg, state, np.float64).train_step_grads(batch, d["perm"], beta=0.05)
+        truth = truth_out["cache"]
+        cal = Calibrated()
+        for l in range(cfg["L"]):
+            cal.check(cache["layers"][l]["pooled"][rs], d[f"train_pooled_{l}"],
+                      truth["layers"][l]["pooled"][rs], what=f"pooled {l}")
+            cal.check(cache["hidden"][l][rs], d[f"train_hidden_{l}"], truth["hidden"][l][rs], what=f"hidden {l}")
+    else:
+        for l in range(cfg["L"]):
+            assert_close(cache["layers"][l]["pooled"][rs], d[f"train_pooled_{l}"], what=f"pooled {l}")
+            assert_close(cache["hidden"][l][rs], d[f"train_hidden_{l}"], what=f"hidden {l}")
+    losses = np.array([out["loss"], out["c_loss"], out["d_loss"]])
+    if case.startswith("true_"):
+        cal.check(out["c_logit"], d["train_c_logit"], truth_out["c_logit"], what="c_logit")
+        cal.check(out["d_logit"], d["train_d_logit"], truth_out["d_logit"], what="d_logit")
+        cal.check(losses, d["train_loss"],
+                  np.array([truth_out["loss"], truth_out["c_loss"], truth_out["d_loss"]]), what="loss")
+    else:
+        assert_close(out["c_logit"], d["train_c_logit"], what="c_logit")
+        assert_close(out["d_logit"], d["train_d_logit"], what="d_logit")
+        assert_close(losses, d["train_loss"], what="loss")
     g = out["grads"]
     checked = 0
     # Gradients accumulate fp32 rounding of the reference's own backward through
@@ -84,7 +102,11 @@ def test_train_step(case, dtype):
     for key in d:
         if key.startswith("grad_"):
             name = key[len("grad_"):]
-            assert_close(g[name].reshape(d[key].shape), d[key], rtol=gtol, what=key, floor=floor)
+            if case.startswith("true_"):
+                Calibrated(gtol).check(g[name].reshape(d[key].shape), d[key],
+                                       truth_out["grads"][name].reshape(d[key].shape), what=key, floor=floor)
+            else:
+                assert_close(g[name].reshape(d[key].shape), d[key], rtol=gtol, what=key, floor=floor)
             checked += 1
         if key.startswith("gradnone_"):
             assert key[len("gradnone_"):] not in g or not cfg["learn_eps"]
