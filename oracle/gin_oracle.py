@@ -314,7 +314,9 @@ class OracleGIN:
             d_h = np.zeros_like(h_in)
             if self.learn_eps:
                 grads.setdefault("eps", np.zeros(L, dtype=dt))
-                grads["eps"][l] = (dpooled * h_in).sum()
+                # heavily cancelling reduction (terms >> result): accumulate in fp64 whatever
+                # the working dtype, as the HIP kernel does
+                grads["eps"][l] = (dpooled.astype(np.float64) * h_in).sum()
                 d_h = d_h + (1 + self.p["eps"][l]) * dpooled
             src = dpooled / deg if self.npool == "average" else dpooled
             d_h = d_h + A.T @ src
