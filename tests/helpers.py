@@ -19,10 +19,14 @@ RTOL = 1e-5
 # checked against the fp64 oracle with the bound
 #     max(RTOL, TRUE_SHAPE_FACTOR * err(reference golden, fp64 oracle)).
 TRUE_SHAPE_FACTOR = 4.0
-# Gradients of the true-shape case are worse conditioned still (d loss / d eps[0]
-# = -51.08 in fp64; the reference's fp32 autograd gives -51.06, a numpy fp32
-# backward -50.96): allow 10x the reference's own deviation from fp64.
-TRUE_SHAPE_GRAD_FACTOR = 10.0
+# Gradients of the true-shape case: the backward multiplies by the ReLU mask, and
+# among 5 x 2 x 51,200 pre-activations a few sit within rounding of zero, so two
+# correct fp32 implementations can disagree on a mask bit.  One flipped bit moves
+# a bias-gradient sum by ~1e-3 relative (measured: numpy-fp32 vs numpy-fp64 differ
+# in exactly one mask element of layer 4 -> 9.8e-4 on batch_norms.4.bias, while
+# the reference happened not to flip).  True-shape gradients are therefore
+# compared with the fp64 oracle at 5e-3; the tiny cases keep 5e-5.
+TRUE_SHAPE_GRAD_RTOL = 5e-3
 
 
 def golden_cases(prefix=""):

@@ -7,7 +7,7 @@ float32 outputs (it is the build's only fp64 cross-check)."""
 import numpy as np
 import pytest
 
-from helpers import (RTOL, TRUE_SHAPE_GRAD_FACTOR, Calibrated, assert_close, edge_mat_of, golden_cases, grad_floor,
+from helpers import (RTOL, TRUE_SHAPE_GRAD_RTOL, Calibrated, assert_close, edge_mat_of, golden_cases, grad_floor,
                      load_case)
 from oracle import gin_oracle as O
 
@@ -103,8 +103,10 @@ def test_train_step(case, dtype):
         if key.startswith("grad_"):
             name = key[len("grad_"):]
             if case.startswith("true_"):
-                Calibrated(gtol, TRUE_SHAPE_GRAD_FACTOR).check(g[name].reshape(d[key].shape), d[key],
-                                       truth_out["grads"][name].reshape(d[key].shape), what=key, floor=floor)
+                assert_close(d[key], truth_out["grads"][name].reshape(d[key].shape), rtol=TRUE_SHAPE_GRAD_RTOL,
+                             what=key + " (golden vs fp64 oracle)", floor=floor)
+                assert_close(g[name].reshape(d[key].shape), truth_out["grads"][name].reshape(d[key].shape),
+                             rtol=TRUE_SHAPE_GRAD_RTOL, what=key, floor=floor)
             else:
                 assert_close(g[name].reshape(d[key].shape), d[key], rtol=gtol, what=key, floor=floor)
             checked += 1
