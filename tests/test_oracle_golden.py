@@ -72,7 +72,8 @@ def test_train_step(case, dtype):
     cache = out["cache"]
     if case.startswith("true_"):
         # deep true-shape activations: calibrated against the fp64 oracle (helpers.TRUE_SHAPE_FACTOR)
-        truth_out = make_model(cfg, state, np.float64).train_step_grads(batch, d["perm"], beta=0.05)
+        truth_model = make_model(cfg, state, np.float64)
+        truth_out = truth_model.train_step_grads(batch, d["perm"], beta=0.05)
         truth = truth_out["cache"]
         cal = Calibrated()
         for l in range(cfg["L"]):
@@ -127,6 +128,8 @@ def test_train_step(case, dtype):
             name = key[len("bufafter_"):]
             if name.endswith("num_batches_tracked"):
                 assert int(model.p[name]) == int(d[key])
+            elif case.startswith("true_"):
+                cal.check(model.p[name], d[key], truth_model.p[name], what=key)
             else:
                 assert_close(model.p[name], d[key], what=key)
 
