@@ -1,0 +1,303 @@
+// GIN neighbour aggregation on gfx950 (MI355X): the K1+K2+K3 fusion of SURVEY.md
+// section 2.2, replacing torch.spmm(Adj_block, h) (+ degree spmm, divide, (1+eps)h)
+// at /root/reference models/graphcnn.py:154-161 and :178-182, and its autograd
+// backward.
+//
+// Design (one workgroup = one graph x one feature slice):
+//   * the block-diagonal matrix is never materialised: each graph keeps a private
+//     CSR (int32 rowptr, uint16 graph-local column ids) in a device-resident arena;
+//   * phase A streams the graph's [n, FS] feature tile from HBM into LDS once,
+//     coalesced (16 B per lane);
+//   * phase B gathers neighbour rows FROM LDS with ds_read_b128: LPR = FS/4 lanes
+//     cover one row, so one wave-instruction reads 64/LPR neighbour rows (1 KiB),
+//     the LDS peak of 256 B/clk/CU.  For LPR == 16 (FS = 64 floats = 256-B rows)
+//     the four 16-lane quarters of a wave each take every 4th neighbour of the SAME
+//     destination row; neighbour ids are fetched 64 at a time with one coalesced
+//     load and handed to the quarters with a DPP row_newbcast folded into the
+//     address VALU (v_or_b32_dpp), so a gather step is 1 VALU + 1 ds_read_b128 +
+//     4 adds.  256-B rows make every 16-lane ds_read_b128 group hit 64 distinct
+//     banks whatever the row ids are (bank = (addr/4) % 64), so there are no
+//     bank conflicts by construction;
+//   * the quarters' partial sums are combined with two wave shuffles, the
+//     mean/(1+eps) epilogue is applied in registers and `pooled` is written once.
+//
+// One kernel serves forward and backward through the identity
+//   y[v] = post[v] * ( sum_{u in N(v)} pre[u] x[u] + selfA * pre[v] x[v] ) + selfB * x[v]
+//   forward : pre = 1,           post = 1/deg' (average) or 1
+//   backward: pre = 1/deg' (avg), post = 1        (gather over the TRANSPOSED CSR)
+//   learn_eps=True : selfA = 0, selfB = 1 + eps[layer], deg' = deg
+//   learn_eps=False: selfA = 1, selfB = 0,             deg' = deg + 1  (self loops,
+//                    graphcnn.py:97-102)
+// In backward it also produces d eps[layer] = sum dpooled * h (fp64 partials).
+#include "gnm_common.h"
+
+struct AggArgs {
+    const int32_t* rowptr;     // gather structure arena (forward CSR, or transposed for backward)
+    const uint16_t* col;       // graph-local column ids
+    const int64_t* b_rp_off;   // [B] offset of graph b's rowptr block
+    const int64_t* b_col_off;  // [B] offset of graph b's col block
+    const int32_t* deg_rowptr; // forward CSR rowptr arena (degrees for the backward pre-scale)
+    const int64_t* b_deg_off;  // [B]
+    const int32_t* node_off;   // [B+1] first row of each graph in the batch
+    const float* x;
+    float* y;
+    const float* eps;          // device pointer to eps[layer], or null
+    const float* hfwd;         // backward: forward input of the layer (for d eps), or null
+    double* deps_partial;      // [B * nslices] or null
+    int ldx, ldy, ldh;
+    int F;                     // valid feature width
+    int nslices;
+    int average, self_loop, backward;
+};
+
+template <int S>
+__device__ __forceinline__ unsigned row_bcast16(unsigned v) {
+    // DPP row_newbcast:S -- every lane of a 16-lane row reads lane S of its row
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + S, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ void acc4(float4& a, const float4 v) {
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+}
+__device__ __forceinline__ void acc4(float4& a, const f32x4 v) {
+    a.x += v[0]; a.y += v[1]; a.z += v[2]; a.w += v[3];
+}
+
+// LDS is addressed through 32-bit address-space-3 pointers built from integers, so
+// that "row base (DPP broadcast) + lane chunk + LDS base" is ONE v_add_u32_dpp
+// feeding ds_read_b128 (a generic char* + offset costs an extra VALU per gather).
+typedef __attribute__((address_space(3))) const f32x4* lds_cf4p;
+__device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
+    return *(lds_cf4p)(uintptr_t)addr;
+}
+
+#define GNM_STEP16(S) acc4(acc, lds_read16(row_bcast16<S>(valb) + subb));
+
+template <int LPR>
+__global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
+    constexpr int FS = LPR * 4;        // floats per LDS row
+    constexpr int SLOTS = 64 / LPR;    // neighbour rows read per wave-instruction
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* tile = reinterpret_cast<float4*>(smem);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int b = blockIdx.x / p.nslices;
+    const int sl = blockIdx.x - b * p.nslices;
+    const int row0 = p.node_off[b];
+    const int n = p.node_off[b + 1] - row0;
+    const int col0 = sl * FS;
+    const int32_t* rp = p.rowptr + p.b_rp_off[b];
+    const uint16_t* cl = p.col + p.b_col_off[b];
+    const int32_t* drp = p.deg_rowptr + p.b_deg_off[b];
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    const bool vec_in = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    const bool vec_h = p.hfwd && ((p.ldh & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.hfwd) & 15) == 0);
+    const bool prescale = p.backward && p.average;
+
+    // ---- phase A: HBM -> LDS, coalesced; optional 1/deg pre-scale and d-eps dot ----
+    double dot = 0.0;
+    for (int i = tid; i < n * LPR; i += nthreads) {
+        const int r = i / LPR;
+        const int c = i - r * LPR;
+        const int cc = col0 + 4 * c;
+        const float* src = p.x + (size_t)(row0 + r) * p.ldx + cc;
+        float4 v;
+        if (vec_in && cc + 3 < p.F) {
+            v = *reinterpret_cast<const float4*>(src);
+        } else {
+            v.x = (cc + 0 < p.F) ? src[0] : 0.f;
+            v.y = (cc + 1 < p.F) ? src[1] : 0.f;
+            v.z = (cc + 2 < p.F) ? src[2] : 0.f;
+            v.w = (cc + 3 < p.F) ? src[3] : 0.f;
+        }
+        if (p.deps_partial) {
+            const float* hs = p.hfwd + (size_t)(row0 + r) * p.ldh + cc;
+            float4 h;
+            if (vec_h && cc + 3 < p.F) {
+                h = *reinterpret_cast<const float4*>(hs);
+            } else {
+                h.x = (cc + 0 < p.F) ? hs[0] : 0.f;
+                h.y = (cc + 1 < p.F) ? hs[1] : 0.f;
+                h.z = (cc + 2 < p.F) ? hs[2] : 0.f;
+                h.w = (cc + 3 < p.F) ? hs[3] : 0.f;
+            }
+            dot += (double)v.x * h.x + (double)v.y * h.y + (double)v.z * h.z + (double)v.w * h.w;
+        }
+        if (prescale) {
+            const float d = (float)(drp[r + 1] - drp[r] + p.self_loop);
+            v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        }
+        tile[i] = v;
+    }
+    if (tid < LPR) tile[n * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // row n = zeros (padding slots)
+    __syncthreads();
+
+    // ---- phase B: gather neighbour rows from LDS --------------------------------
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = nthreads >> 6;
+    const int sub = lane & (LPR - 1);          // 16-B chunk of the row this lane owns
+    const int slot = lane / LPR;               // which of the SLOTS concurrent neighbours
+    const unsigned subb = lds_base + (unsigned)sub * 16u;   // LDS byte address of this lane's chunk in row 0
+    const int jlane = sub * SLOTS + slot;      // edge (within a 64-chunk) whose id this lane fetches
+    const unsigned zero_row_b = (unsigned)n * (FS * 4);
+    const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
+    const bool vec_out = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+
+    // y == null: only the d-eps dot product of phase A is wanted
+    for (int v = p.y ? wave : n; v < n; v += nwaves) {
+        const int beg = rp[v];
+        const int end = rp[v + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e0 = beg; e0 < end; e0 += 64) {
+            const int cnt = min(64, end - e0);
+            unsigned valb = zero_row_b;
+            if (jlane < cnt) valb = (unsigned)cl[e0 + jlane] * (FS * 4);
+            const int steps = (cnt + SLOTS - 1) / SLOTS;   // wave-uniform
+            if constexpr (LPR == 16) {
+                if (steps == 16) {
+                    GNM_STEP16(0) GNM_STEP16(1) GNM_STEP16(2) GNM_STEP16(3)
+                    GNM_STEP16(4) GNM_STEP16(5) GNM_STEP16(6) GNM_STEP16(7)
+                    GNM_STEP16(8) GNM_STEP16(9) GNM_STEP16(10) GNM_STEP16(11)
+                    GNM_STEP16(12) GNM_STEP16(13) GNM_STEP16(14) GNM_STEP16(15)
+                } else {
+                    if (steps > 0) GNM_STEP16(0)
+                    if (steps > 1) GNM_STEP16(1)
+                    if (steps > 2) GNM_STEP16(2)
+                    if (steps > 3) GNM_STEP16(3)
+                    if (steps > 4) GNM_STEP16(4)
+                    if (steps > 5) GNM_STEP16(5)
+                    if (steps > 6) GNM_STEP16(6)
+                    if (steps > 7) GNM_STEP16(7)
+                    if (steps > 8) GNM_STEP16(8)
+                    if (steps > 9) GNM_STEP16(9)
+                    if (steps > 10) GNM_STEP16(10)
+                    if (steps > 11) GNM_STEP16(11)
+                    if (steps > 12) GNM_STEP16(12)
+                    if (steps > 13) GNM_STEP16(13)
+                    if (steps > 14) GNM_STEP16(14)
+                }
+            } else {
+                const int gbase = lane & ~(LPR - 1);
+                for (int s = 0; s < steps; ++s) {
+                    acc4(acc, lds_read16((unsigned)__shfl((int)valb, gbase + s, 64) + subb));
+                }
+            }
+        }
+        // combine the SLOTS partial sums of this destination row
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+            acc.z += __shfl_xor(acc.z, off, 64);
+            acc.w += __shfl_xor(acc.w, off, 64);
+        }
+        if (lane < LPR) {
+            const float4 self = tile[v * LPR + sub];
+            if (p.self_loop) acc4(acc, self);
+            if (!p.backward && p.average) {
+                const float d = (float)(end - beg + p.self_loop);   // 0/0 -> NaN as in the reference
+                acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
+            }
+            const int cc = col0 + 4 * sub;
+            if (!p.self_loop) {
+                float4 sb = self;
+                if (prescale) {   // the tile holds dp/deg; the (1+eps) term needs dp itself
+                    const float* src = p.x + (size_t)(row0 + v) * p.ldx + cc;
+                    sb.x = (cc + 0 < p.F) ? src[0] : 0.f;
+                    sb.y = (cc + 1 < p.F) ? src[1] : 0.f;
+                    sb.z = (cc + 2 < p.F) ? src[2] : 0.f;
+                    sb.w = (cc + 3 < p.F) ? src[3] : 0.f;
+                }
+                acc.x += selfB * sb.x; acc.y += selfB * sb.y; acc.z += selfB * sb.z; acc.w += selfB * sb.w;
+            }
+            float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
+            if (vec_out && cc + 3 < p.F) {
+                *reinterpret_cast<float4*>(dst) = acc;
+            } else {
+                if (cc + 0 < p.F) dst[0] = acc.x;
+                if (cc + 1 < p.F) dst[1] = acc.y;
+                if (cc + 2 < p.F) dst[2] = acc.z;
+                if (cc + 3 < p.F) dst[3] = acc.w;
+            }
+        }
+    }
+
+    if (p.deps_partial) {   // block reduction of the d-eps dot product (fp64, fixed order)
+        __syncthreads();    // everyone is done reading the tile; reuse its first bytes
+        double* red = reinterpret_cast<double*>(smem);
+        const double w = wave_sum_d(dot);
+        if (lane == 0) red[wave] = w;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < nwaves; ++i) s += red[i];
+            p.deps_partial[blockIdx.x] = s;
+        }
+    }
+}
+
+template <int LPR>
+static int launch_agg(const AggArgs& a, int B, int n_max, hipStream_t stream) {
+    const size_t lds = (size_t)(n_max + 1) * LPR * 16;
+    static size_t configured = 0;
+    if (lds > configured) {
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg_kernel<LPR>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        configured = kLdsBudget;
+    }
+    // one workgroup per CU when the tile is large (16 waves to keep the LDS pipe busy);
+    // smaller tiles share a CU, so use fewer waves per workgroup.
+    int threads = 1024;
+    if (lds <= 20 * 1024) threads = 256;
+    else if (lds <= 48 * 1024) threads = 512;
+    hipLaunchKernelGGL(gnm_agg_kernel<LPR>, dim3(B * a.nslices), dim3(threads), lds, stream, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// Feature-slice width (floats) the launcher will use for width F and the largest
+// graph of the batch; 0 when even the narrowest slice does not fit in LDS.
+extern "C" int gnm_agg_slice_width(int F, int n_max) {
+    int fs = 8;
+    while (fs < F && fs < 128) fs <<= 1;
+    while (fs >= 8 && (size_t)(n_max + 1) * fs * 4 > (size_t)kLdsBudget - 1024) fs >>= 1;
+    return fs >= 8 ? fs : 0;
+}
+
+extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
+                       const int64_t* b_col_off, const int32_t* deg_rowptr, const int64_t* b_deg_off,
+                       const int32_t* node_off, int B, int n_max, const float* x, int ldx, float* y, int ldy,
+                       int F, const float* eps, int average, int self_loop, int backward, const float* hfwd,
+                       int ldh, double* deps_partial, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (F <= 0 || n_max < 0 || n_max > 65535) return GNM_ERR_BAD_ARG;
+    const int fs = gnm_agg_slice_width(F, n_max);
+    if (fs == 0) return GNM_ERR_UNSUPPORTED;   // graph too large for an LDS-resident slice
+    AggArgs a;
+    a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
+    a.deg_rowptr = deg_rowptr ? deg_rowptr : rowptr;
+    a.b_deg_off = b_deg_off ? b_deg_off : b_rp_off;
+    a.node_off = node_off; a.x = x; a.y = y; a.eps = eps; a.hfwd = hfwd; a.deps_partial = deps_partial;
+    a.ldx = ldx; a.ldy = ldy; a.ldh = ldh; a.F = F;
+    a.nslices = (F + fs - 1) / fs;
+    a.average = average; a.self_loop = self_loop; a.backward = backward;
+    if (deps_partial && !hfwd) return GNM_ERR_BAD_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (fs) {
+        case 8: return launch_agg<2>(a, B, n_max, s);
+        case 16: return launch_agg<4>(a, B, n_max, s);
+        case 32: return launch_agg<8>(a, B, n_max, s);
+        case 64: return launch_agg<16>(a, B, n_max, s);
+        case 128: return launch_agg<32>(a, B, n_max, s);
+    }
+    return GNM_ERR_UNSUPPORTED;
+}
+
+// Number of deps partials gnm_agg writes for (F, n_max, B): B * nslices.
+extern "C" int gnm_agg_num_partials(int F, int n_max, int B) {
+    const int fs = gnm_agg_slice_width(F, n_max);
+    if (fs == 0) return 0;
+    return B * ((F + fs - 1) / fs);
+}

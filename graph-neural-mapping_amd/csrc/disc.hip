@@ -1,0 +1,143 @@
+// Deep-Graph-Infomax scorer of the GIN_InfoMaxReg tail (K10/K11 of SURVEY.md section 2.2):
+// /root/reference models/discriminator.py:19-38 called from models/graphcnn.py:233-246.
+//
+// The reference expands every graph summary c[g] to all of its nodes and evaluates
+// nn.Bilinear(LH, LH, 1) on [N, LH] x [N, LH] (2*N*2*LH^2 FLOP).  Algebraically
+//     sc_1[v] = n_f[v]      . U[g(v)] + b,     U = sigmoid(g_f) W^T   ([B, LH], tiny GEMM)
+//     sc_2[v] = n_f[idx[v]] . U[g(v)] + b,     idx[v] = perm[g(v)]    (a ROW index < B:
+//                                                                       graphcnn.py:198-201,242)
+// so the N-sized work is one HBM-bound row-dot over the L hidden layers; sc_2 is constant
+// inside a graph.  n_f (torch.cat(hidden_rep, 1), graphcnn.py:233) is never materialised:
+// the kernels take the L per-layer [N, H] buffers.
+#include "gnm_common.h"
+
+#define GNM_MAX_LAYERS 16
+struct HPtrs {
+    const float* p[GNM_MAX_LAYERS];
+};
+
+// d_logit[v] = sc_1[v], d_logit[N + v] = sc_2[g(v)]; one workgroup per graph, one wave per row.
+__global__ void __launch_bounds__(256) gnm_disc_score_kernel(const HPtrs hp, int ldh, int L, int H,
+                                                             const float* __restrict__ U, int ldu,
+                                                             const int32_t* __restrict__ perm_rows,
+                                                             const float* __restrict__ bias,
+                                                             const int32_t* __restrict__ node_off, int N,
+                                                             float* __restrict__ d_logit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Us = reinterpret_cast<float*>(smem);        // [L*H]
+    float* sc2s = Us + L * H;                          // [1]
+    const int g = blockIdx.x;
+    const int row0 = node_off[g];
+    const int n = node_off[g + 1] - row0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < L * H; e += 256) Us[e] = U[(size_t)g * ldu + e];
+    __syncthreads();
+    const float bv = bias ? bias[0] : 0.f;
+    if (wave == 0) {
+        const int pr = perm_rows[g];
+        float a = 0.f;
+        for (int l = 0; l < L; ++l)
+            for (int c = lane; c < H; c += 64) a += hp.p[l][(size_t)pr * ldh + c] * Us[l * H + c];
+        a = wave_sum(a);
+        if (lane == 0) sc2s[0] = a + bv;
+    }
+    __syncthreads();
+    const float sc2 = sc2s[0];
+    for (int r = wave; r < n; r += 4) {
+        const int v = row0 + r;
+        float a = 0.f;
+        for (int l = 0; l < L; ++l)
+            for (int c = lane; c < H; c += 64) a += hp.p[l][(size_t)v * ldh + c] * Us[l * H + c];
+        a = wave_sum(a);
+        if (lane == 0) {
+            d_logit[v] = a + bv;
+            d_logit[(size_t)N + v] = sc2;
+        }
+    }
+}
+
+extern "C" int gnm_disc_score_fwd(const float* const* hptrs, int ldh, int L, int H, const float* U, int ldu,
+                                  const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
+                                  float* d_logit, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (L <= 0 || L > GNM_MAX_LAYERS || H <= 0) return GNM_ERR_BAD_ARG;
+    HPtrs hp;
+    for (int l = 0; l < GNM_MAX_LAYERS; ++l) hp.p[l] = l < L ? hptrs[l] : nullptr;
+    hipLaunchKernelGGL(gnm_disc_score_kernel, dim3(B), dim3(256), (size_t)(L * H + 4) * 4,
+                       reinterpret_cast<hipStream_t>(stream), hp, ldh, L, H, U, ldu, perm_rows, bias, node_off, N,
+                       d_logit);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// Backward wrt U (and the per-graph sum of the negative-branch gradient):
+//   s2sum[g]  = sum_{v in g} dD[N + v]
+//   dU[g, l*H + c] = sum_{v in g} dD[v] * h_l[v, c] + s2sum[g] * h_l[perm_rows[g], c]
+// (the gradient wrt n_f itself is folded into gnm_bn_relu_bwd_stats).
+__global__ void __launch_bounds__(256) gnm_disc_du_kernel(const HPtrs hp, int ldh, int L, int H,
+                                                          const float* __restrict__ dD,
+                                                          const int32_t* __restrict__ perm_rows,
+                                                          const int32_t* __restrict__ node_off, int N,
+                                                          float* __restrict__ dU, int ldu,
+                                                          float* __restrict__ s2sum) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* red = reinterpret_cast<float4*>(smem);     // [RP][H4]
+    __shared__ float wsum[4];
+    const int g = blockIdx.x;
+    const int row0 = node_off[g];
+    const int n = node_off[g + 1] - row0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f;
+    for (int r = tid; r < n; r += 256) s += dD[(size_t)N + row0 + r];
+    s = wave_sum(s);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    const float s2 = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (tid == 0) s2sum[g] = s2;
+    const int H4 = H >> 2;
+    const int RP = 256 / H4;
+    const int rg = tid / H4, c4 = tid - rg * H4;
+    const int pr = perm_rows[g];
+    for (int l = 0; l < L; ++l) {
+        const float* hl = hp.p[l];
+        if (rg < RP) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int r = rg; r < n; r += RP) {
+                const int v = row0 + r;
+                const float w = dD[v];
+                const float4 x = *reinterpret_cast<const float4*>(hl + (size_t)v * ldh + 4 * c4);
+                acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
+            }
+            red[rg * H4 + c4] = acc;
+        }
+        __syncthreads();
+        if (tid < H4) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < RP; ++q) {
+                const float4 x = red[q * H4 + tid];
+                t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+            }
+            const float4 x = *reinterpret_cast<const float4*>(hl + (size_t)pr * ldh + 4 * tid);
+            t.x += s2 * x.x; t.y += s2 * x.y; t.z += s2 * x.z; t.w += s2 * x.w;
+            *reinterpret_cast<float4*>(dU + (size_t)g * ldu + (size_t)l * H + 4 * tid) = t;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int gnm_disc_score_bwd(const float* const* hptrs, int ldh, int L, int H, const float* dD,
+                                  const int32_t* perm_rows, const int32_t* node_off, int N, int B, float* dU, int ldu,
+                                  float* s2sum, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (L <= 0 || L > GNM_MAX_LAYERS || H <= 0 || (H & 3) || H > 1024 || (ldh & 3) || (ldu & 3))
+        return GNM_ERR_BAD_ARG;
+    HPtrs hp;
+    for (int l = 0; l < GNM_MAX_LAYERS; ++l) hp.p[l] = l < L ? hptrs[l] : nullptr;
+    const int H4 = H >> 2, RP = 256 / H4;
+    hipLaunchKernelGGL(gnm_disc_du_kernel, dim3(B), dim3(256), (size_t)RP * H4 * 16,
+                       reinterpret_cast<hipStream_t>(stream), hp, ldh, L, H, dD, perm_rows, node_off, N, dU, ldu,
+                       s2sum);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}

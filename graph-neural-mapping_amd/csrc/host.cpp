@@ -1,0 +1,91 @@
+// Host-side helpers of the C-ABI: per-graph CSR construction from the reference's
+// edge_mat ([2, E] int64, util.py:99-103) -- the device-resident replacement for
+// GIN_InfoMaxReg.__preprocess_neighbors_sumavepool (/root/reference
+// models/graphcnn.py:84-106) -- and the inverse expansion used by the parity tests to
+// prove the CSR encodes the identical edge multiset and offsets.
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+extern "C" {
+
+const char* gnm_version(void) { return "gnm_hip 0.1 (gfx950)"; }
+
+// rowptr[n+1], col[E]: row = edge_mat[0][e], col = edge_mat[1][e]; edges of a row keep
+// their edge_mat order (stable counting sort); duplicates are kept (COO duplicates add).
+int gnm_csr_from_edge_mat(const int64_t* edge_mat, long long E, int n, int32_t* rowptr, uint16_t* col) {
+    if (n < 0 || n > 65535 || E < 0) return -1;
+    const int64_t* src = edge_mat;
+    const int64_t* dst = edge_mat + E;
+    for (int i = 0; i <= n; ++i) rowptr[i] = 0;
+    for (long long e = 0; e < E; ++e) {
+        if (src[e] < 0 || src[e] >= n || dst[e] < 0 || dst[e] >= n) return -2;
+        rowptr[src[e] + 1]++;
+    }
+    for (int i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
+    std::vector<int32_t> fill(rowptr, rowptr + n);
+    for (long long e = 0; e < E; ++e) col[fill[src[e]]++] = (uint16_t)dst[e];
+    return 0;
+}
+
+int gnm_csr_transpose(const int32_t* rowptr, const uint16_t* col, int n, int32_t* rowptr_t, uint16_t* col_t) {
+    const int32_t E = rowptr[n];
+    for (int i = 0; i <= n; ++i) rowptr_t[i] = 0;
+    for (int32_t e = 0; e < E; ++e) rowptr_t[col[e] + 1]++;
+    for (int i = 0; i < n; ++i) rowptr_t[i + 1] += rowptr_t[i];
+    std::vector<int32_t> fill(rowptr_t, rowptr_t + n);
+    for (int r = 0; r < n; ++r)
+        for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) col_t[fill[col[e]]++] = (uint16_t)r;
+    return 0;
+}
+
+// 1 when A and A^T hold the same edge multiset (then the backward may gather over A itself)
+int gnm_csr_is_symmetric(const int32_t* rowptr, const uint16_t* col, int n) {
+    const int32_t E = rowptr[n];
+    std::vector<int32_t> rpt(n + 1);
+    std::vector<uint16_t> ct(E > 0 ? E : 1);
+    gnm_csr_transpose(rowptr, col, n, rpt.data(), ct.data());
+    if (memcmp(rpt.data(), rowptr, sizeof(int32_t) * (n + 1)) != 0) return 0;
+    std::vector<uint16_t> row;
+    for (int r = 0; r < n; ++r) {
+        row.assign(col + rowptr[r], col + rowptr[r + 1]);
+        std::sort(row.begin(), row.end());
+        if (!std::equal(row.begin(), row.end(), ct.begin() + rowptr[r])) return 0;   // A^T rows come out sorted
+    }
+    return 1;
+}
+
+// Expand a batch of per-graph CSRs to the reference's block-diagonal COO index
+// (Adj_block._indices(), graphcnn.py:91-104): out[0][e] = row + start[b],
+// out[1][e] = col + start[b], row-major by (graph, row, CSR position); when
+// self_loops != 0 the N self loops are appended as the reference does (:97-102).
+// Returns the number of entries written.
+long long gnm_batch_coo_from_csr(const int32_t* rowptr_arena, const uint16_t* col_arena, const int64_t* b_rp_off,
+                                 const int64_t* b_col_off, const int32_t* node_off, int B, int self_loops,
+                                 int64_t* out_rows, int64_t* out_cols) {
+    long long k = 0;
+    for (int b = 0; b < B; ++b) {
+        const int32_t* rp = rowptr_arena + b_rp_off[b];
+        const uint16_t* cl = col_arena + b_col_off[b];
+        const int n = node_off[b + 1] - node_off[b];
+        for (int r = 0; r < n; ++r)
+            for (int32_t e = rp[r]; e < rp[r + 1]; ++e) {
+                out_rows[k] = (int64_t)node_off[b] + r;
+                out_cols[k] = (int64_t)node_off[b] + cl[e];
+                ++k;
+            }
+    }
+    if (self_loops) {
+        const int N = node_off[B];
+        for (int v = 0; v < N; ++v) {
+            out_rows[k] = v;
+            out_cols[k] = v;
+            ++k;
+        }
+    }
+    return k;
+}
+
+}  // extern "C"

@@ -1,0 +1,472 @@
+// The per-layer MLP contraction of the GIN update (K4 of SURVEY.md section 2.2):
+// nn.Linear at /root/reference models/mlp.py:25,32-35,43,48,49, forward and the two
+// backward products autograd derives (dX = dZ W, dW = dZ^T X, db = sum dZ), on the
+// exact-fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32; gfx950 has no xf32).
+//
+// Shapes are tall and skinny ([N, K] x [K, H], N ~ 4e5, K, H <= 128), so:
+//   * the whole weight matrix lives in LDS, k-major, for the kernel's lifetime;
+//   * each wave owns 32-row tiles of X.  A tile is staged through a wave-private,
+//     padded LDS image with full-line 16-B loads (fragment-shaped global loads
+//     would touch 32 lines per instruction), where the fused prologue
+//     relu(x*scale+shift) -- the BatchNorm+ReLU of the previous Linear
+//     (mlp.py:48) -- is applied on the fly;
+//   * the MFMA k order is permuted (k = (KC/2)*half + step) so a lane's KC/2
+//     A-operands are contiguous in LDS and come in with ds_read_b128, conflict-free
+//     at a row stride of KC+4 floats;
+//   * the epilogue adds the bias, stores Z, and accumulates per-column sum and sum
+//     of squares (fp64) for the BatchNorm that follows (mlp.py:48, graphcnn.py:163):
+//     in the 32x32 C/D layout a lane owns one output COLUMN, so the statistics are
+//     register adds.
+#include "gnm_common.h"
+
+struct LinArgs {
+    const float* X;
+    const float* W;
+    const float* bias;       // [H] or null
+    float* Z;
+    const float* pro_scale;  // [K] prologue x*scale+shift (then relu if pro_relu), or null
+    const float* pro_shift;
+    double* stats_partial;   // [gridDim.x][2][H] or null
+    int ldx, ldw, ldz;
+    int N, K, H;
+    int w_kmajor;            // 0: W[h*ldw+k] (torch Linear weight);  1: W[k*ldw+h]
+    int pro_relu;
+};
+
+template <int KC, int HT>
+__global__ void __launch_bounds__(256) gnm_lin_kernel(const LinArgs p) {
+    constexpr int HP = HT * 32;          // padded output width
+    constexpr int XS = KC + 4;           // staging row stride (floats): conflict-free ds_read_b128
+    constexpr int C4 = KC / 4;           // float4 per staged row
+    constexpr int KH = KC / 2;           // MFMA steps per chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nchunks = (p.K + KC - 1) / KC;
+    const int KP = nchunks * KC;
+    float* Wt = reinterpret_cast<float*>(smem);                   // [KP][HP]
+    float* Xs_all = Wt + (size_t)KP * HP;                         // [4][32][XS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    float* Xs = Xs_all + wave * 32 * XS;
+
+    // ---- stage W^T (k-major, zero padded) --------------------------------------
+    if (p.w_kmajor) {
+        for (int idx = tid; idx < KP * HP; idx += 256) {
+            const int k = idx / HP, hh = idx - k * HP;
+            Wt[idx] = (k < p.K && hh < p.H) ? p.W[(size_t)k * p.ldw + hh] : 0.f;
+        }
+    } else {
+        for (int idx = tid; idx < KP * HP; idx += 256) {
+            const int hh = idx / KP, k = idx - hh * KP;
+            Wt[k * HP + hh] = (k < p.K && hh < p.H) ? p.W[(size_t)hh * p.ldw + k] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const bool vec_in = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.X) & 15) == 0);
+    const int ntiles = (p.N + 31) / 32;
+    double st1[HT], st2[HT];
+#pragma unroll
+    for (int c = 0; c < HT; ++c) { st1[c] = 0.0; st2[c] = 0.0; }
+    float bias_r[HT];
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        const int col = 32 * c + i;
+        bias_r[c] = (p.bias && col < p.H) ? p.bias[col] : 0.f;
+    }
+    const int c4 = lane % C4;            // loop-invariant: 64 % C4 == 0
+
+    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+        const int r0 = t * 32;
+        f32x16 acc[HT];
+#pragma unroll
+        for (int c = 0; c < HT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int kb = kc * KC;
+            // -- stage the [32][KC] chunk of X (coalesced), fused prologue --
+            const int k4 = kb + 4 * c4;
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.pro_scale) {
+                sc.x = (k4 + 0 < p.K) ? p.pro_scale[k4 + 0] : 0.f; sh.x = (k4 + 0 < p.K) ? p.pro_shift[k4 + 0] : 0.f;
+                sc.y = (k4 + 1 < p.K) ? p.pro_scale[k4 + 1] : 0.f; sh.y = (k4 + 1 < p.K) ? p.pro_shift[k4 + 1] : 0.f;
+                sc.z = (k4 + 2 < p.K) ? p.pro_scale[k4 + 2] : 0.f; sh.z = (k4 + 2 < p.K) ? p.pro_shift[k4 + 2] : 0.f;
+                sc.w = (k4 + 3 < p.K) ? p.pro_scale[k4 + 3] : 0.f; sh.w = (k4 + 3 < p.K) ? p.pro_shift[k4 + 3] : 0.f;
+            }
+#pragma unroll
+            for (int idx = lane; idx < 32 * C4; idx += 64) {
+                const int row = idx / C4;
+                const int grow = r0 + row;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (grow < p.N) {
+                    const float* src = p.X + (size_t)grow * p.ldx + k4;
+                    if (vec_in && k4 + 3 < p.K) {
+                        v = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        if (k4 + 0 < p.K) v.x = src[0];
+                        if (k4 + 1 < p.K) v.y = src[1];
+                        if (k4 + 2 < p.K) v.z = src[2];
+                        if (k4 + 3 < p.K) v.w = src[3];
+                    }
+                    if (p.pro_scale) {
+                        v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
+                        v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                        if (p.pro_relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                    }
+                }
+                *reinterpret_cast<float4*>(Xs + row * XS + 4 * c4) = v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // -- A fragments: lane (i, h) takes X[r0+i][kb + KH*h + s], s = 0..KH-1 --
+            float a[KH];
+#pragma unroll
+            for (int j = 0; j < KH / 4; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 4 * j);
+                a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+            }
+            const float* wrow = Wt + (size_t)(kb + KH * h) * HP + i;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) {
+#pragma unroll
+                for (int c = 0; c < HT; ++c) {
+                    const float bv = wrow[s * HP + 32 * c];
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv, acc[c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // A fragments are in registers before Xs is overwritten
+        }
+
+        // ---- epilogue: bias, store, BatchNorm statistics ----------------------
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            const int col = 32 * c + i;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float z = acc[c][r] + bias_r[c];
+                if (grow < p.N && col < p.H) {
+                    p.Z[(size_t)grow * p.ldz + col] = z;
+                    s1 += z;
+                    s2 += z * z;
+                }
+            }
+            st1[c] += (double)s1;
+            st2[c] += (double)s2;
+        }
+    }
+
+    if (p.stats_partial) {   // block-level combine in a fixed order, one partial row per block
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);   // [4 waves][2][HP]
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            const double a1 = st1[c] + __shfl_xor(st1[c], 32, 64);
+            const double a2 = st2[c] + __shfl_xor(st2[c], 32, 64);
+            if (h == 0) {
+                red[(wave * 2 + 0) * HP + 32 * c + i] = a1;
+                red[(wave * 2 + 1) * HP + 32 * c + i] = a2;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * HP; idx += 256) {
+            const int which = idx / HP, col = idx - which * HP;
+            if (col < p.H) {
+                double s = 0.0;
+                for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * HP + col];
+                p.stats_partial[((size_t)blockIdx.x * 2 + which) * p.H + col] = s;
+            }
+        }
+    }
+}
+
+static size_t lin_lds_bytes(int K, int KC, int HT) {
+    const int KP = ((K + KC - 1) / KC) * KC;
+    size_t b = (size_t)KP * HT * 32 * 4 + (size_t)4 * 32 * (KC + 4) * 4;
+    const size_t red = (size_t)4 * 2 * HT * 32 * 8;
+    return b > red ? b : red;
+}
+
+template <int KC, int HT>
+static int launch_lin(const LinArgs& a, int grid, hipStream_t s) {
+    const size_t lds = lin_lds_bytes(a.K, KC, HT);
+    if (lds > (size_t)kLdsBudget) return GNM_ERR_UNSUPPORTED;
+    static bool configured = false;
+    if (!configured) {
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_lin_kernel<KC, HT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gnm_lin_kernel<KC, HT>), dim3(grid), dim3(256), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// Blocks gnm_linear_fwd launches for N rows (= rows of stats_partial it writes).
+extern "C" int gnm_linear_grid(int N) {
+    const int ntiles = (N + 31) / 32;
+    int g = (ntiles + 3) / 4;
+    if (g > 768) g = 768;
+    return g < 1 ? 1 : g;
+}
+
+// Z[N,H] = f(X)[N,K] * W^T + bias, f = optional fused affine(+ReLU) prologue; optional
+// per-column (sum, sum of squares) partials for the following BatchNorm.
+extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, int w_kmajor, const float* bias,
+                              float* Z, int ldz, int N, int K, int H, const float* pro_scale,
+                              const float* pro_shift, int pro_relu, double* stats_partial, void* stream) {
+    if (N <= 0) return GNM_OK;
+    if (K <= 0 || H <= 0 || H > 128) return GNM_ERR_BAD_ARG;
+    LinArgs a;
+    a.X = X; a.W = W; a.bias = bias; a.Z = Z; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
+    a.stats_partial = stats_partial; a.ldx = ldx; a.ldw = ldw; a.ldz = ldz; a.N = N; a.K = K; a.H = H;
+    a.w_kmajor = w_kmajor; a.pro_relu = pro_relu;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = gnm_linear_grid(N);
+    const int HT = (H + 31) / 32;
+    const int kc = K <= 8 ? 8 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64));
+#define GNM_LIN_CASE(KC_, HT_) if (kc == KC_ && HT == HT_) return launch_lin<KC_, HT_>(a, grid, s);
+    GNM_LIN_CASE(8, 1) GNM_LIN_CASE(8, 2) GNM_LIN_CASE(8, 3) GNM_LIN_CASE(8, 4)
+    GNM_LIN_CASE(16, 1) GNM_LIN_CASE(16, 2) GNM_LIN_CASE(16, 3) GNM_LIN_CASE(16, 4)
+    GNM_LIN_CASE(32, 1) GNM_LIN_CASE(32, 2) GNM_LIN_CASE(32, 3) GNM_LIN_CASE(32, 4)
+    GNM_LIN_CASE(64, 1) GNM_LIN_CASE(64, 2) GNM_LIN_CASE(64, 3) GNM_LIN_CASE(64, 4)
+#undef GNM_LIN_CASE
+    return GNM_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------
+// weight gradient: dW[h][k] = sum_n dZ[n][h] * f(X)[n][k],  db[h] = sum_n dZ[n][h]
+// MFMA 32x32x2 with the batch row as the contraction index: lane (i, half) feeds
+// A = dZ[n+half][32*ti+i] and B = f(X)[n+half][32*tj+i] straight from global memory
+// (128-B contiguous per half-wave).  Each block reduces its row range to one
+// [H x KW] partial; gnm_reduce_partials sums the partials in a fixed order.
+// ------------------------------------------------------------------------------
+struct WgArgs {
+    const float* dZ;
+    const float* X;
+    const float* pro_scale;  // [K] or null
+    const float* pro_shift;
+    float* partial;          // [gridDim.x][H*kw + H]
+    int ldd, ldx;
+    int N, H, K;
+    int k0, kw;              // column window of X handled by this launch (kw <= 128)
+    int rows_per_block;      // even
+    int pro_relu;
+};
+
+template <int WI, int WJ, int QI, int QJ>
+__global__ void __launch_bounds__(256) gnm_wgrad_kernel(const WgArgs p) {
+    constexpr int NQ = QI * QJ;          // quadrants of the output, one per wave group
+    constexpr int RSPLIT = 4 / NQ;       // waves sharing a quadrant split the rows
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dump = reinterpret_cast<float*>(smem);   // [4][WI*WJ][16][64] (+ db [4][WI][64])
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int q = wave % NQ, rs = wave / NQ;
+    const int qi = q / QJ, qj = q % QJ;
+
+    f32x16 acc[WI][WJ];
+#pragma unroll
+    for (int a = 0; a < WI; ++a)
+#pragma unroll
+        for (int b = 0; b < WJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float dbacc[WI];
+#pragma unroll
+    for (int a = 0; a < WI; ++a) dbacc[a] = 0.f;
+
+    int hcol[WI], kcol[WJ];
+    bool hok[WI], kok[WJ];
+    float sc[WJ], sh[WJ];
+#pragma unroll
+    for (int a = 0; a < WI; ++a) { hcol[a] = 32 * (qi * WI + a) + i; hok[a] = hcol[a] < p.H; }
+#pragma unroll
+    for (int b = 0; b < WJ; ++b) {
+        const int kl = 32 * (qj * WJ + b) + i;       // column inside the window
+        kcol[b] = p.k0 + kl;
+        kok[b] = (kl < p.kw) && (kcol[b] < p.K);
+        sc[b] = (p.pro_scale && kok[b]) ? p.pro_scale[kcol[b]] : 1.f;
+        sh[b] = (p.pro_scale && kok[b]) ? p.pro_shift[kcol[b]] : 0.f;
+    }
+
+    const int rb = blockIdx.x * p.rows_per_block;
+    const int re = min(p.N, rb + p.rows_per_block);
+#pragma unroll 4
+    for (int n0 = rb + 2 * rs; n0 < re; n0 += 2 * RSPLIT) {
+        const int n = n0 + h;
+        const bool rok = n < re;
+        float av[WI], bv[WJ];
+#pragma unroll
+        for (int a = 0; a < WI; ++a) av[a] = (rok && hok[a]) ? p.dZ[(size_t)n * p.ldd + hcol[a]] : 0.f;
+#pragma unroll
+        for (int b = 0; b < WJ; ++b) {
+            float x = 0.f;
+            if (rok && kok[b]) {
+                x = p.X[(size_t)n * p.ldx + kcol[b]];
+                if (p.pro_scale) {
+                    x = x * sc[b] + sh[b];
+                    if (p.pro_relu) x = fmaxf(x, 0.f);
+                }
+            }
+            bv[b] = x;
+        }
+#pragma unroll
+        for (int a = 0; a < WI; ++a) {
+            dbacc[a] += av[a];
+#pragma unroll
+            for (int b = 0; b < WJ; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- dump per-wave accumulators, then combine waves in a fixed order ---------
+    constexpr int TILE = 16 * 64;
+    float* mine = dump + (size_t)wave * WI * WJ * TILE;
+#pragma unroll
+    for (int a = 0; a < WI; ++a)
+#pragma unroll
+        for (int b = 0; b < WJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(a * WJ + b) * TILE + r * 64 + lane] = acc[a][b][r];
+    float* dbdump = dump + (size_t)4 * WI * WJ * TILE;   // [4][WI][64]
+#pragma unroll
+    for (int a = 0; a < WI; ++a) dbdump[(wave * WI + a) * 64 + lane] = dbacc[a];
+    __syncthreads();
+
+    float* out = p.partial + (size_t)blockIdx.x * ((size_t)p.H * p.kw + p.H);
+    for (int idx = tid; idx < NQ * WI * WJ * TILE; idx += 256) {
+        const int qq = idx / (WI * WJ * TILE);
+        const int rem = idx - qq * (WI * WJ * TILE);
+        const int ab = rem / TILE;
+        const int rl = rem - ab * TILE;
+        const int r = rl >> 6, ln = rl & 63;
+        const int a = ab / WJ, b = ab - a * WJ;
+        const int row = 32 * ((qq / QJ) * WI + a) + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int colw = 32 * ((qq % QJ) * WJ + b) + (ln & 31);
+        if (row < p.H && colw < p.kw) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < RSPLIT; ++w) s += dump[(size_t)(w * NQ + qq) * WI * WJ * TILE + rem];
+            out[(size_t)row * p.kw + colw] = s;
+        }
+    }
+    // bias gradient: only the qj == 0 quadrants hold each dZ column exactly once
+    for (int idx = tid; idx < QI * WI * 32; idx += 256) {
+        const int qqi = idx / (WI * 32);
+        const int rem = idx - qqi * (WI * 32);
+        const int a = rem >> 5, ii = rem & 31;
+        const int hh = 32 * (qqi * WI + a) + ii;
+        if (hh < p.H) {
+            float s = 0.f;
+            const int qq = qqi * QJ;     // qj == 0
+#pragma unroll
+            for (int w = 0; w < RSPLIT; ++w) {
+                const int wv = w * NQ + qq;
+                s += dbdump[(wv * WI + a) * 64 + ii] + dbdump[(wv * WI + a) * 64 + 32 + ii];
+            }
+            out[(size_t)p.H * p.kw + hh] = s;
+        }
+    }
+}
+
+template <int WI, int WJ, int QI, int QJ>
+static int launch_wgrad(const WgArgs& a, int grid, hipStream_t s) {
+    const size_t lds = ((size_t)4 * WI * WJ * 1024 + (size_t)4 * WI * 64) * 4;
+    static bool configured = false;
+    if (!configured) {
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_wgrad_kernel<WI, WJ, QI, QJ>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gnm_wgrad_kernel<WI, WJ, QI, QJ>), dim3(grid), dim3(256), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+extern "C" int gnm_wgrad_grid(int N) {
+    int g = (N + 511) / 512;            // >= 512 rows per block
+    if (g > 512) g = 512;
+    return g < 1 ? 1 : g;
+}
+
+// Floats of workspace gnm_linear_wgrad needs: grid * (H*min(K,128) + H).
+extern "C" long long gnm_wgrad_workspace_floats(int N, int H, int K) {
+    const int kw = K < 128 ? K : 128;
+    return (long long)gnm_wgrad_grid(N) * ((long long)H * kw + H);
+}
+
+// Second stage: sum the per-block partials in a fixed order and scatter the
+// [H x kw] window into dW (leading dimension ldw, column offset k0) and db.
+__global__ void gnm_reduce_partials_kernel(const float* __restrict__ partial, int nblk, long long stride, int H,
+                                           int kw, int k0, float* __restrict__ dW, int ldw,
+                                           float* __restrict__ db) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int count = H * kw + H;
+    if (e >= count) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += partial[(size_t)(b + 0) * stride + e];
+        s1 += partial[(size_t)(b + 1) * stride + e];
+        s2 += partial[(size_t)(b + 2) * stride + e];
+        s3 += partial[(size_t)(b + 3) * stride + e];
+    }
+    for (; b < nblk; ++b) s0 += partial[(size_t)b * stride + e];
+    const float s = (s0 + s1) + (s2 + s3);
+    if (e < H * kw) {
+        const int row = e / kw, col = e - row * kw;
+        dW[(size_t)row * ldw + k0 + col] = s;
+    } else if (db && k0 == 0) {
+        db[e - H * kw] = s;
+    }
+}
+
+// dW[H,K] (row-major, ld = ldw) and db[H] from dZ[N,H] and f(X)[N,K].  `workspace`
+// must hold gnm_wgrad_workspace_floats(N,H,K) floats.
+extern "C" int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ldx, int N, int H, int K,
+                                const float* pro_scale, const float* pro_shift, int pro_relu, float* dW, int ldw,
+                                float* db, float* workspace, void* stream) {
+    if (H <= 0 || K <= 0 || H > 128) return GNM_ERR_BAD_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = gnm_wgrad_grid(N > 0 ? N : 1);
+    int rpb = ((N > 0 ? N : 1) + grid - 1) / grid;
+    rpb = (rpb + 1) & ~1;
+    const int HT = (H + 31) / 32;
+    for (int k0 = 0; k0 < K; k0 += 128) {
+        const int kw = (K - k0) < 128 ? (K - k0) : 128;
+        const int KT = (kw + 31) / 32;
+        WgArgs a;
+        a.dZ = dZ; a.X = X; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.partial = workspace;
+        a.ldd = ldd; a.ldx = ldx; a.N = N; a.H = H; a.K = K; a.k0 = k0; a.kw = kw; a.rows_per_block = rpb;
+        a.pro_relu = pro_relu;
+        const int WI = HT < 2 ? HT : 2, WJ = KT < 2 ? KT : 2;
+        const int QI = (HT + WI - 1) / WI, QJ = (KT + WJ - 1) / WJ;
+        int rc = GNM_ERR_UNSUPPORTED;
+#define GNM_WG_CASE(WI_, WJ_, QI_, QJ_) \
+    if (WI == WI_ && WJ == WJ_ && QI == QI_ && QJ == QJ_) rc = launch_wgrad<WI_, WJ_, QI_, QJ_>(a, grid, s);
+        GNM_WG_CASE(1, 1, 1, 1) GNM_WG_CASE(1, 2, 1, 1) GNM_WG_CASE(1, 2, 1, 2)
+        GNM_WG_CASE(2, 1, 1, 1) GNM_WG_CASE(2, 2, 1, 1) GNM_WG_CASE(2, 2, 1, 2)
+        GNM_WG_CASE(2, 1, 2, 1) GNM_WG_CASE(2, 2, 2, 1) GNM_WG_CASE(2, 2, 2, 2)
+#undef GNM_WG_CASE
+        if (rc != GNM_OK) return rc;
+        const long long stride = (long long)H * kw + H;
+        const int count = H * kw + H;
+        hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 255) / 256), dim3(256), 0, s, workspace, grid,
+                           stride, H, kw, k0, dW, ldw, db);
+        GNM_CHECK_LAUNCH();
+    }
+    return GNM_OK;
+}

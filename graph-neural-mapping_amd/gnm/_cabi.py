@@ -1,0 +1,71 @@
+"""ctypes binding of libgnm_hip.so (include/gnm_hip.h).
+
+There is deliberately no fallback: if the library is missing or a symbol does not
+resolve, importing this module raises, and every call checks the returned status.
+"""
+import ctypes as C
+import os
+
+from . import _build
+
+_c_f32p = C.c_void_p   # device pointers travel as plain integers (tensor.data_ptr())
+_i, _ll, _f, _p = C.c_int, C.c_longlong, C.c_float, C.c_void_p
+
+# name -> (restype, [argtypes]); order and meaning exactly as in include/gnm_hip.h
+SIGNATURES = {
+    "gnm_version": (C.c_char_p, []),
+    "gnm_csr_from_edge_mat": (_i, [_p, _ll, _i, _p, _p]),
+    "gnm_csr_transpose": (_i, [_p, _p, _i, _p, _p]),
+    "gnm_csr_is_symmetric": (_i, [_p, _p, _i]),
+    "gnm_batch_coo_from_csr": (_ll, [_p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "gnm_agg": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p]),
+    "gnm_agg_slice_width": (_i, [_i, _i]),
+    "gnm_agg_num_partials": (_i, [_i, _i, _i]),
+    "gnm_sum_partials": (_i, [_p, _i, _p, _p]),
+    "gnm_linear_grid": (_i, [_i]),
+    "gnm_linear_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),
+    "gnm_wgrad_grid": (_i, [_i]),
+    "gnm_wgrad_workspace_floats": (_ll, [_i, _i, _i]),
+    "gnm_linear_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _i, _p, _i, _p, _p, _p]),
+    "gnm_bn_finalize": (_i, [_p, _i, _i, _ll, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p]),
+    "gnm_bn_relu_readout": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p]),
+    "gnm_bn_relu_bwd_stats": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p,
+                                   _i, _i, _p, _p]),
+    "gnm_bn_bwd_finalize": (_i, [_p, _i, _i, _ll, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "gnm_bn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _ll, _i, _p]),
+    "gnm_disc_score_fwd": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p]),
+    "gnm_disc_score_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p]),
+}
+
+
+class GnmError(RuntimeError):
+    pass
+
+
+def _load():
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        raise GnmError(
+            "libgnm_hip.so not found at %s -- build it first (python __graft_entry__.py, or "
+            "python graph-neural-mapping_amd/gnm/_build.py).  There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+_STATUS = {-1: "GNM_ERR_BAD_ARG", -2: "GNM_ERR_UNSUPPORTED"}
+
+
+def check(status, what):
+    if status != 0:
+        raise GnmError("%s failed: %s" % (what, _STATUS.get(status, "hipError %d" % status)))
+
+
+def ptr(t):
+    """device/host pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,190 @@
+"""Device-resident graph arena and batch descriptors.
+
+Replaces the per-forward host work of GIN_InfoMaxReg.__preprocess_neighbors_sumavepool
+(/root/reference models/graphcnn.py:84-106: int64 block-diagonal COO rebuilt and copied
+H2D every forward, 780 MB at B=1024), __preprocess_graphpool (:109-134, O(N) Python
+loops) and the X_concat H2D copy (:195).  Each S2VGraph-like object is converted ONCE to
+a graph-local CSR (int32 rowptr, uint16 columns) and uploaded with its node features;
+a batch is then just B graph ids, from which three small offset vectors are gathered on
+the device.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._cabi import check, lib
+
+
+class _Growable:
+    """1-D device buffer with amortised doubling growth."""
+
+    def __init__(self, dtype, device, width=None):
+        self.dtype, self.device, self.width = dtype, device, width
+        self.size = 0
+        shape = (0,) if width is None else (0, width)
+        self.buf = torch.empty(shape, dtype=dtype, device=device)
+
+    def append(self, host_tensor):
+        k = host_tensor.shape[0]
+        need = self.size + k
+        if need > self.buf.shape[0]:
+            cap = max(need, 2 * self.buf.shape[0], 1024)
+            shape = (cap,) if self.width is None else (cap, self.width)
+            nb = torch.empty(shape, dtype=self.dtype, device=self.device)
+            nb[: self.size].copy_(self.buf[: self.size])
+            self.buf = nb
+        self.buf[self.size:need].copy_(host_tensor, non_blocking=False)
+        off = self.size
+        self.size = need
+        return off
+
+
+class Batch:
+    """What the kernels need to know about one batch of graphs (all on the device)."""
+
+    __slots__ = ("B", "N", "n_max", "n_min", "arena", "node_off", "rp_off", "col_off", "t_rp_off", "t_col_off",
+                 "gids", "node_off_host", "symmetric")
+
+    @property
+    def equal_n(self):
+        return self.n_max == self.n_min
+
+
+class GraphArena:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.rowptr = _Growable(torch.int32, self.device)
+        self.col = _Growable(torch.int16, self.device)      # uint16 payload
+        self.feat = None                                    # created on first add (needs F0)
+        self.n, self.rp_off, self.col_off, self.t_rp_off, self.t_col_off, self.feat_off, self.nnz = [], [], [], [], [], [], []
+        self.sym = []
+        self._dev_tables = None
+        self._token = object()
+
+    def __len__(self):
+        return len(self.n)
+
+    # ------------------------------------------------------------------ build
+    def add(self, graph):
+        """Convert one S2VGraph-like object (fields: g, edge_mat, node_features;
+        util.py:9-17) and return its arena id.  Cached on the object."""
+        cached = getattr(graph, "_gnm_cache", None)
+        if cached is not None and cached[0] is self._token:
+            return cached[1]
+        n = len(graph.g)
+        em = graph.edge_mat
+        em = em.detach().cpu().numpy() if torch.is_tensor(em) else np.asarray(em)
+        em = np.ascontiguousarray(em, dtype=np.int64).reshape(2, -1)
+        feats = graph.node_features
+        feats = feats.detach().cpu() if torch.is_tensor(feats) else torch.as_tensor(np.asarray(feats))
+        feats = feats.to(torch.float32).contiguous()
+        gid = self.add_raw(n, em, feats)
+        try:
+            graph._gnm_cache = (self._token, gid)
+        except Exception:
+            pass
+        return gid
+
+    def add_raw(self, n, edge_mat, feats):
+        E = edge_mat.shape[1]
+        rowptr = np.empty(n + 1, dtype=np.int32)
+        col = np.empty(max(E, 1), dtype=np.uint16)
+        check(lib.gnm_csr_from_edge_mat(edge_mat.ctypes.data, E, n, rowptr.ctypes.data, col.ctypes.data),
+              "gnm_csr_from_edge_mat")
+        col = col[:E]
+        sym = bool(lib.gnm_csr_is_symmetric(rowptr.ctypes.data, col.ctypes.data if E else None, n)) if E else True
+        rp_off = self.rowptr.append(torch.from_numpy(rowptr))
+        col_off = self.col.append(torch.from_numpy(col.view(np.int16)))
+        if sym:
+            t_rp_off, t_col_off = rp_off, col_off
+        else:
+            rpt = np.empty(n + 1, dtype=np.int32)
+            ct = np.empty(max(E, 1), dtype=np.uint16)
+            check(lib.gnm_csr_transpose(rowptr.ctypes.data, col.ctypes.data, n, rpt.ctypes.data, ct.ctypes.data),
+                  "gnm_csr_transpose")
+            t_rp_off = self.rowptr.append(torch.from_numpy(rpt))
+            t_col_off = self.col.append(torch.from_numpy(ct[:E].view(np.int16)))
+        if self.feat is None:
+            self.feat = _Growable(torch.float32, self.device, width=feats.shape[1])
+        if feats.shape != (n, self.feat.width):
+            raise ValueError("node_features must be [n, %d], got %s" % (self.feat.width, tuple(feats.shape)))
+        feat_off = self.feat.append(feats)
+        self.n.append(n); self.nnz.append(E); self.sym.append(sym)
+        self.rp_off.append(rp_off); self.col_off.append(col_off)
+        self.t_rp_off.append(t_rp_off); self.t_col_off.append(t_col_off); self.feat_off.append(feat_off)
+        self._dev_tables = None
+        return len(self.n) - 1
+
+    def _tables(self):
+        if self._dev_tables is None:
+            d = self.device
+            t = lambda x, dt: torch.tensor(x, dtype=dt, device=d)
+            self._dev_tables = dict(n=t(self.n, torch.int64), rp=t(self.rp_off, torch.int64),
+                                    col=t(self.col_off, torch.int64), trp=t(self.t_rp_off, torch.int64),
+                                    tcol=t(self.t_col_off, torch.int64), feat=t(self.feat_off, torch.int64),
+                                    n_host=np.asarray(self.n, dtype=np.int64),
+                                    sym_host=np.asarray(self.sym, dtype=bool))
+        return self._dev_tables
+
+    # ------------------------------------------------------------------ batches
+    def batch(self, graphs):
+        gids = [self.add(g) for g in graphs]
+        return self.batch_from_gids(torch.tensor(gids, dtype=torch.int64))
+
+    def batch_from_gids(self, gids):
+        """gids: int64 tensor (host or device) of arena ids."""
+        tb = self._tables()
+        gh = gids.cpu().numpy() if torch.is_tensor(gids) else np.asarray(gids, dtype=np.int64)
+        gd = torch.as_tensor(gh, dtype=torch.int64).to(self.device, non_blocking=True)
+        ns = tb["n_host"][gh]
+        b = Batch()
+        b.arena = self
+        b.B = int(gh.shape[0])
+        b.gids = gd
+        b.n_max, b.n_min = int(ns.max()), int(ns.min())
+        node_off_host = np.zeros(b.B + 1, dtype=np.int64)
+        np.cumsum(ns, out=node_off_host[1:])
+        b.node_off_host = node_off_host
+        b.N = int(node_off_host[-1])
+        b.node_off = torch.as_tensor(node_off_host.astype(np.int32)).to(self.device, non_blocking=True)
+        b.rp_off = tb["rp"][gd]
+        b.col_off = tb["col"][gd]
+        b.symmetric = bool(tb["sym_host"][gh].all())
+        if b.symmetric:
+            b.t_rp_off, b.t_col_off = b.rp_off, b.col_off
+        else:
+            b.t_rp_off, b.t_col_off = tb["trp"][gd], tb["tcol"][gd]
+        return b
+
+    def features(self, batch):
+        """X_concat (graphcnn.py:195) gathered on the device: [N, F0] fp32."""
+        tb = self._tables()
+        if batch.equal_n:
+            base = tb["feat"][batch.gids]
+            idx = (base[:, None] + torch.arange(batch.n_max, device=self.device)[None, :]).reshape(-1)
+        else:
+            ns = tb["n"][batch.gids]
+            base = torch.repeat_interleave(tb["feat"][batch.gids], ns)
+            start = torch.repeat_interleave(torch.as_tensor(batch.node_off_host[:-1], device=self.device), ns)
+            idx = base + (torch.arange(batch.N, device=self.device) - start)
+        return self.feat.buf.index_select(0, idx)
+
+    # ------------------------------------------------------------------ parity export
+    def export_adj_coo(self, batch, self_loops):
+        """The reference's Adj_block._indices() (graphcnn.py:91-104) rebuilt from the
+        arena, for the bit-exact index tests.  Host int64 [2, nnz(+N)]."""
+        tb = self._tables()
+        gh = batch.gids.cpu().numpy()
+        nnz = int(np.asarray(self.nnz, dtype=np.int64)[gh].sum()) + (batch.N if self_loops else 0)
+        rowptr_h = self.rowptr.buf[: self.rowptr.size].cpu().numpy()
+        col_h = self.col.buf[: self.col.size].cpu().numpy().view(np.uint16)
+        rp_off = batch.rp_off.cpu().numpy().astype(np.int64)
+        col_off = batch.col_off.cpu().numpy().astype(np.int64)
+        node_off = batch.node_off_host.astype(np.int32)
+        out = np.empty((2, max(nnz, 1)), dtype=np.int64)
+        k = lib.gnm_batch_coo_from_csr(rowptr_h.ctypes.data, col_h.ctypes.data, rp_off.ctypes.data,
+                                       col_off.ctypes.data, node_off.ctypes.data, batch.B, int(bool(self_loops)),
+                                       out[0].ctypes.data, out[1].ctypes.data)
+        assert k == nnz, (k, nnz)
+        return out[:, :nnz]

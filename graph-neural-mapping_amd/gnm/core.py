@@ -1,0 +1,305 @@
+"""Forward/backward orchestration of the GIN hot path over the C-ABI kernels.
+
+One torch.autograd.Function (GinInfoMaxFn) covers everything GIN_InfoMaxReg.forward
+computes after batch assembly (/root/reference models/graphcnn.py:208-251): the L GIN
+layers (neighbour aggregation -> MLP -> BatchNorm -> ReLU), the per-layer graph readout and
+classifier, and the Infomax discriminator scores.  Its backward is hand-derived (the same
+derivation as oracle/gin_oracle.py, which the tests check it against) and launches the
+HIP kernels of csrc/ directly; torch only provides device memory, the stream, and a few
+tiny [B, .] dense ops (classifier Linear(H, C), U = sigmoid(g_f) W^T).
+
+Every N-sized array op runs in libgnm_hip.so.  There is no CPU or eager-PyTorch fallback
+for the sum/average path: on a non-GPU tensor the calls raise.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from ._cabi import GnmError, check, lib, ptr
+
+BN_EPS = 1e-5       # nn.BatchNorm1d defaults (mlp.py:38, graphcnn.py:51)
+BN_MOMENTUM = 0.1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class GinSpec:
+    """Static description of the model: which parameter tensor is which."""
+
+    def __init__(self, num_layers, num_mlp_layers, learn_eps, graph_pooling_type, neighbor_pooling_type):
+        self.L, self.m = num_layers, num_mlp_layers
+        self.learn_eps = bool(learn_eps)
+        self.g_avg = graph_pooling_type == "average"
+        self.n_avg = neighbor_pooling_type == "average"
+
+
+def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None):
+    """y = None: only the d-eps partials are produced (no gather)."""
+    a = batch.arena
+    if backward:
+        rp_off, col_off = batch.t_rp_off, batch.t_col_off
+    else:
+        rp_off, col_off = batch.rp_off, batch.col_off
+    check(lib.gnm_agg(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), rp_off.data_ptr(), col_off.data_ptr(),
+                      a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), batch.B,
+                      batch.n_max, x.data_ptr(), x.stride(0), ptr(y), y.stride(0) if y is not None else 0, F_,
+                      eps_ptr, int(spec.n_avg), int(not spec.learn_eps), int(backward), ptr(hfwd),
+                      hfwd.stride(0) if hfwd is not None else 0, ptr(deps_partial), _stream()), "gnm_agg")
+
+
+def _linear(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
+    check(lib.gnm_linear_fwd(x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), int(w_kmajor), ptr(bias),
+                             z.data_ptr(), z.stride(0), N, K, H, ptr(pro[0]) if pro else None,
+                             ptr(pro[1]) if pro else None, 1 if pro else 0, ptr(stats), _stream()), "gnm_linear_fwd")
+
+
+def _linear_wide(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
+    """H > 128 (only dX of a wide first layer): column windows of 128."""
+    if H <= 128:
+        return _linear(x, W, w_kmajor, bias, z, N, K, H, pro, stats)
+    assert stats is None
+    for h0 in range(0, H, 128):
+        hw = min(128, H - h0)
+        Wv = W[:, h0:h0 + hw] if w_kmajor else W[h0:h0 + hw]
+        _linear(x, Wv, w_kmajor, bias[h0:h0 + hw] if bias is not None else None, z[:, h0:h0 + hw], N, K, hw, pro, None)
+
+
+class _LinSave:
+    __slots__ = ("x_in", "pro", "z", "scale", "shift", "mean", "rstd", "K", "H")
+
+
+def encoder_forward(spec, batch, X, P, training, update_running):
+    """The L GIN layers + readout.  P: dict of parameter/buffer tensors keyed by the
+    reference's state_dict names.  Returns (hidden list, g_f [B, L*H], saved)."""
+    dev = X.device
+    N, B = batch.N, batch.B
+    L, m = spec.L, spec.m
+    H = P["batch_norms.0.weight"].shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    g_f = torch.empty((B, L * H), **f32)
+    hidden, saved = [], []
+    h = X
+    for l in range(L):
+        F_l = h.shape[1]
+        pooled = torch.empty((N, F_l), **f32)
+        eps_ptr = P["eps"].data_ptr() + 4 * l if spec.learn_eps else None
+        _agg(batch, h, pooled, F_l, eps_ptr, spec, backward=False)        # graphcnn.py:154-161 / 178-182
+        x_in, pro, lins = pooled, None, []
+        for k in range(m):                                                   # mlp.py:40-49
+            if m == 1:
+                W, bias = P[f"mlps.{l}.linear.weight"], P[f"mlps.{l}.linear.bias"]
+            else:
+                W, bias = P[f"mlps.{l}.linears.{k}.weight"], P[f"mlps.{l}.linears.{k}.bias"]
+            bn = f"batch_norms.{l}" if k == m - 1 else f"mlps.{l}.batch_norms.{k}"
+            Hk, K = W.shape
+            z = torch.empty((N, Hk), **f32)
+            grid = lib.gnm_linear_grid(N)
+            stats = torch.empty((grid, 2, Hk), dtype=torch.float64, device=dev) if training else None
+            _linear(x_in, W, 0, bias, z, N, K, Hk, pro, stats)
+            sv = _LinSave()
+            sv.x_in, sv.pro, sv.z, sv.K, sv.H = x_in, pro, z, K, Hk
+            sv.scale, sv.shift, sv.mean, sv.rstd = (torch.empty(Hk, **f32) for _ in range(4))
+            check(lib.gnm_bn_finalize(ptr(stats), grid, Hk, N, P[bn + ".weight"].data_ptr(),
+                                      P[bn + ".bias"].data_ptr(), P[bn + ".running_mean"].data_ptr(),
+                                      P[bn + ".running_var"].data_ptr(),
+                                      P[bn + ".num_batches_tracked"].data_ptr(), BN_MOMENTUM, BN_EPS,
+                                      int(training), int(update_running), sv.scale.data_ptr(), sv.shift.data_ptr(),
+                                      sv.mean.data_ptr(), sv.rstd.data_ptr(), _stream()), "gnm_bn_finalize")
+            lins.append(sv)
+            x_in, pro = z, (sv.scale, sv.shift)
+        hout = torch.empty((N, H), **f32)
+        gslice = g_f[:, l * H:(l + 1) * H]
+        check(lib.gnm_bn_relu_readout(x_in.data_ptr(), x_in.stride(0), pro[0].data_ptr(), pro[1].data_ptr(),
+                                      hout.data_ptr(), hout.stride(0), batch.node_off.data_ptr(), B, H, 1,
+                                      gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), _stream()),
+              "gnm_bn_relu_readout")                                          # graphcnn.py:163-166, 228-229
+        saved.append((h, pooled, lins))
+        hidden.append(hout)
+        h = hout
+    return hidden, g_f, saved
+
+
+def _hptr_array(hidden):
+    arr = (C.c_void_p * len(hidden))(*[t.data_ptr() for t in hidden])
+    return arr
+
+
+class GinInfoMaxFn(torch.autograd.Function):
+    """(X, *params) -> (c_logit [B,C], d_logit [2N,1], g_f [B,L*H])."""
+
+    @staticmethod
+    def forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, X, *tensors):
+        if not X.is_cuda:
+            raise GnmError("the GIN hot path runs on the GPU only (libgnm_hip.so); got a %s tensor" % X.device)
+        ctx.set_materialize_grads(False)
+        P = dict(zip(names, tensors))
+        P.update(buffers)
+        L = spec.L
+        N, B = batch.N, batch.B
+        X = X.contiguous()
+        hidden, g_f, saved = encoder_forward(spec, batch, X, P, training, update_running=training)
+        H = hidden[0].shape[1]
+        # classifier (graphcnn.py:224-231): tiny [B,H] x [H,C] products, torch on device
+        c_logit = None
+        masks = []
+        for l in range(L):
+            lg = F.linear(g_f[:, l * H:(l + 1) * H], P[f"linears_prediction.{l}.weight"],
+                          P[f"linears_prediction.{l}.bias"])
+            if training and dropout_p > 0:
+                mk = F.dropout(torch.ones_like(lg), dropout_p, True)
+                lg = lg * mk
+                masks.append(mk)
+            else:
+                masks.append(None)
+            c_logit = lg if c_logit is None else c_logit + lg
+        d_logit = None
+        c = U = perm_rows = None
+        if want_disc:
+            if not batch.equal_n:
+                raise RuntimeError("Discriminator expands each graph summary N//B times (discriminator.py:24): "
+                                   "all graphs of a batch must have the same number of nodes")
+            c = torch.sigmoid(g_f)                                            # graphcnn.py:239
+            Wd = P["disc.f_k.weight"][0]
+            U = c @ Wd.t()                                                    # U[g] = W c_g
+            perm_rows = torch.as_tensor(perm, dtype=torch.int32).to(X.device)  # row index = perm[g] (:198-201,242)
+            d_logit = torch.empty((2 * N, 1), dtype=torch.float32, device=X.device)
+            check(lib.gnm_disc_score_fwd(_hptr_array(hidden), hidden[0].stride(0), L, H, U.data_ptr(), U.stride(0),
+                                         perm_rows.data_ptr(), P["disc.f_k.bias"].data_ptr(),
+                                         batch.node_off.data_ptr(), N, B, d_logit.data_ptr(), _stream()),
+                  "gnm_disc_score_fwd")
+        ctx.spec, ctx.batch, ctx.names, ctx.P = spec, batch, names, P
+        ctx.hidden, ctx.saved, ctx.g_f, ctx.masks = hidden, saved, g_f, masks
+        ctx.c, ctx.U, ctx.perm_rows, ctx.perm = c, U, perm_rows, perm
+        ctx.training, ctx.X = training, X
+        ctx.mark_non_differentiable(g_f)
+        if d_logit is None:
+            d_logit = torch.zeros((0, 1), dtype=torch.float32, device=X.device)
+        return c_logit, d_logit, g_f
+
+    @staticmethod
+    def backward(ctx, dC, dD, _dgf):
+        spec, batch, P = ctx.spec, ctx.batch, ctx.P
+        L, m = spec.L, spec.m
+        N, B = batch.N, batch.B
+        hidden, saved, g_f = ctx.hidden, ctx.saved, ctx.g_f
+        H = hidden[0].shape[1]
+        dev = g_f.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = _stream()
+        grads = {}
+        need_dx = ctx.needs_input_grad[8]
+
+        # ---- discriminator (discriminator.py:28-36) --------------------------------
+        dsc1 = U = inv_perm = s2sum = None
+        dg_f = None
+        if dD is not None and ctx.U is not None:
+            dD = dD.contiguous().view(-1)
+            U, c = ctx.U, ctx.c
+            dU = torch.empty_like(U)
+            s2sum = torch.empty(B, **f32)
+            check(lib.gnm_disc_score_bwd(_hptr_array(hidden), hidden[0].stride(0), L, H, dD.data_ptr(),
+                                         ctx.perm_rows.data_ptr(), batch.node_off.data_ptr(), N, B, dU.data_ptr(),
+                                         dU.stride(0), s2sum.data_ptr(), st), "gnm_disc_score_bwd")
+            Wd = P["disc.f_k.weight"][0]
+            grads["disc.f_k.weight"] = (dU.t() @ c).unsqueeze(0)
+            grads["disc.f_k.bias"] = dD.sum().reshape(1)
+            dg_f = (dU @ Wd) * c * (1 - c)                                    # sigmoid backward
+            dsc1 = dD                                                         # first N entries = d sc_1
+            inv = torch.empty(B, dtype=torch.int64)
+            inv[torch.as_tensor(ctx.perm, dtype=torch.int64)] = torch.arange(B, dtype=torch.int64)
+            inv_perm = inv.to(torch.int32).to(dev)
+
+        # ---- classifier ---------------------------------------------------------------
+        dph = []
+        for l in range(L):
+            d = None
+            if dC is not None:
+                dlg = dC if ctx.masks[l] is None else dC * ctx.masks[l]
+                Wp = P[f"linears_prediction.{l}.weight"]
+                grads[f"linears_prediction.{l}.weight"] = dlg.t() @ g_f[:, l * H:(l + 1) * H]
+                grads[f"linears_prediction.{l}.bias"] = dlg.sum(0)
+                d = dlg @ Wp
+            if dg_f is not None:
+                d = dg_f[:, l * H:(l + 1) * H] if d is None else d + dg_f[:, l * H:(l + 1) * H]
+            dph.append(d.contiguous() if d is not None else None)
+
+        deps = torch.zeros(L, **f32) if spec.learn_eps else None
+        dH_next = None
+        dX = None
+        for l in reversed(range(L)):
+            h_in, pooled, lins = saved[l]
+            F_l = h_in.shape[1]
+            incoming = dH_next                       # grad wrt this layer's output from the layer above
+            for k in reversed(range(m)):
+                sv = lins[k]
+                Hk, K = sv.H, sv.K
+                last = k == m - 1
+                bn = f"batch_norms.{l}" if last else f"mlps.{l}.batch_norms.{k}"
+                G = torch.empty((N, Hk), **f32)
+                part = torch.empty((B, 2, Hk), dtype=torch.float64, device=dev)
+                dp = dph[l] if last else None
+                use_disc = last and dsc1 is not None
+                Ul = U[:, l * H:(l + 1) * H] if use_disc else None
+                check(lib.gnm_bn_relu_bwd_stats(
+                    ptr(incoming), incoming.stride(0) if incoming is not None else 0,
+                    ptr(dp), dp.stride(0) if dp is not None else 0, int(spec.g_avg),
+                    ptr(dsc1) if use_disc else None, ptr(Ul), U.stride(0) if use_disc else 0,
+                    ptr(inv_perm) if use_disc else None, ptr(s2sum) if use_disc else None,
+                    sv.z.data_ptr(), sv.z.stride(0), sv.scale.data_ptr(), sv.shift.data_ptr(), sv.mean.data_ptr(),
+                    sv.rstd.data_ptr(), 1, G.data_ptr(), G.stride(0), batch.node_off.data_ptr(), B, Hk,
+                    part.data_ptr(), st), "gnm_bn_relu_bwd_stats")
+                dgamma, dbeta, cA, m1, m2 = (torch.empty(Hk, **f32) for _ in range(5))
+                check(lib.gnm_bn_bwd_finalize(part.data_ptr(), B, Hk, N, P[bn + ".weight"].data_ptr(),
+                                              sv.rstd.data_ptr(), int(ctx.training), dgamma.data_ptr(),
+                                              dbeta.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), st),
+                      "gnm_bn_bwd_finalize")
+                grads[bn + ".weight"], grads[bn + ".bias"] = dgamma, dbeta
+                check(lib.gnm_bn_bwd_apply(G.data_ptr(), G.stride(0), sv.z.data_ptr(), sv.z.stride(0),
+                                           sv.mean.data_ptr(), sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(),
+                                           m2.data_ptr(), G.data_ptr(), G.stride(0), N, Hk, st), "gnm_bn_bwd_apply")
+                dZ = G
+                wname = f"mlps.{l}.linear" if m == 1 else f"mlps.{l}.linears.{k}"
+                W = P[wname + ".weight"]
+                dW = torch.empty_like(W)
+                db = torch.empty(Hk, **f32)
+                ws = torch.empty(int(lib.gnm_wgrad_workspace_floats(N, Hk, K)), **f32)
+                check(lib.gnm_linear_wgrad(dZ.data_ptr(), dZ.stride(0), sv.x_in.data_ptr(), sv.x_in.stride(0), N, Hk,
+                                           K, ptr(sv.pro[0]) if sv.pro else None, ptr(sv.pro[1]) if sv.pro else None,
+                                           1 if sv.pro else 0, dW.data_ptr(), dW.stride(0), db.data_ptr(),
+                                           ws.data_ptr(), st), "gnm_linear_wgrad")
+                grads[wname + ".weight"], grads[wname + ".bias"] = dW, db
+                # dX of this Linear: always for inner Linears; for the first one only when the
+                # aggregation backward below has a consumer (a lower layer, dX, or d eps[l])
+                if k > 0 or l > 0 or need_dx or spec.learn_eps:
+                    dA = torch.empty((N, K), **f32)                            # dX = dZ W
+                    _linear_wide(dZ, W, 1, None, dA, N, Hk, K, None, None)
+                    incoming = dA
+                else:
+                    incoming = None
+            # aggregation backward: d h_{l-1} = A^T (dpooled [/deg]) + (1+eps) dpooled ; d eps[l]
+            if incoming is not None:
+                dpooled = incoming
+                want_dh = l > 0 or need_dx
+                dh = torch.empty((N, F_l), **f32) if want_dh else None
+                part = None
+                if spec.learn_eps:
+                    part = torch.empty(lib.gnm_agg_num_partials(F_l, batch.n_max, B), dtype=torch.float64, device=dev)
+                eps_ptr = P["eps"].data_ptr() + 4 * l if spec.learn_eps else None
+                _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True, hfwd=h_in if spec.learn_eps else None,
+                     deps_partial=part)
+                if spec.learn_eps:
+                    check(lib.gnm_sum_partials(part.data_ptr(), part.numel(), deps.data_ptr() + 4 * l, st),
+                          "gnm_sum_partials")
+                if l > 0:
+                    dH_next = dh
+                else:
+                    dX = dh
+        if spec.learn_eps:
+            grads["eps"] = deps
+        out = [None] * 8 + [dX if need_dx else None]
+        for i, name in enumerate(ctx.names):
+            out.append(grads.get(name) if ctx.needs_input_grad[9 + i] else None)
+        return tuple(out)

@@ -1,0 +1,180 @@
+"""GIN_InfoMaxReg on MI355X: the reference's model interface over the HIP hot path.
+
+Drop-in for /root/reference models/graphcnn.py (class at :12, constructor :13, forward
+:194, compute_saliency :254): `from models.graphcnn import *` in the reference's main.py
+(main.py:9) resolves to this file when main.py is run from graph-neural-mapping_amd/.
+Constructor arguments, submodule names / creation order (=> identical seeded init and
+state_dict keys), numpy-RNG consumption (one np.random.permutation(B) per forward,
+graphcnn.py:199), return values and error behaviour follow the reference.
+
+What differs is how the work is done: graphs are converted once to a device-resident CSR
+arena (gnm/arena.py), and everything from `X_concat` on runs in libgnm_hip.so through one
+autograd.Function with a hand-written backward (gnm/core.py).  The sum / average
+neighbour-pooling paths have no CPU or eager fallback -- on a CPU device forward() raises.
+neighbor_pooling_type == "max" is outside the accelerated path and
+runs as plain torch ops, for API compatibility only.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+for _p in (_PKG, _HERE):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from mlp import MLP  # noqa: E402
+from discriminator import Discriminator  # noqa: E402
+from gnm.arena import GraphArena  # noqa: E402
+from gnm.core import GinInfoMaxFn, GinSpec  # noqa: E402
+
+__all__ = ["GIN_InfoMaxReg", "GraphCNN", "MLP", "Discriminator"]
+
+
+class GIN_InfoMaxReg(nn.Module):
+    def __init__(self, num_layers, num_mlp_layers, input_dim, hidden_dim, output_dim, final_dropout, learn_eps,
+                 graph_pooling_type, neighbor_pooling_type, device):
+        super().__init__()
+        # creation order follows graphcnn.py:29-52 so torch.manual_seed(s) yields the same weights
+        self.disc = Discriminator(hidden_dim * num_layers)
+        self.sigm = nn.Sigmoid()
+        self.relu = nn.ReLU()
+        self.final_dropout = final_dropout
+        self.device = device
+        self.num_layers = num_layers
+        self.num_mlp_layers = num_mlp_layers
+        self.graph_pooling_type = graph_pooling_type
+        self.neighbor_pooling_type = neighbor_pooling_type
+        self.learn_eps = learn_eps
+        self.eps = nn.Parameter(torch.zeros(num_layers))
+        self.mlps = nn.ModuleList()
+        self.batch_norms = nn.ModuleList()
+        self.linears_prediction = nn.ModuleList()
+        for layer in range(num_layers):
+            self.mlps.append(MLP(num_mlp_layers, input_dim if layer == 0 else hidden_dim, hidden_dim, hidden_dim))
+            self.batch_norms.append(nn.BatchNorm1d(hidden_dim))
+            self.linears_prediction.append(nn.Linear(hidden_dim, output_dim))
+        self._spec = GinSpec(num_layers, num_mlp_layers, learn_eps, graph_pooling_type, neighbor_pooling_type)
+        self._arena = None
+
+    # ------------------------------------------------------------------ plumbing
+    def arena(self):
+        """Device-resident graph store; created lazily on the parameters' device."""
+        dev = self.eps.device
+        if self._arena is None or self._arena.device != dev:
+            self._arena = GraphArena(dev)
+        return self._arena
+
+    def _run(self, batch, X, perm, want_disc):
+        names, tensors = zip(*self.named_parameters())
+        buffers = dict(self.named_buffers())
+        return GinInfoMaxFn.apply(self._spec, batch, perm, names, buffers, self.training, float(self.final_dropout),
+                                  want_disc, X, *tensors)
+
+    def forward_batch(self, batch, X=None, perm=None, latent=False):
+        """forward() for an already assembled gnm.arena.Batch (what bench.py and the
+        data-parallel driver call: no per-graph Python work)."""
+        if perm is None:
+            perm = np.random.permutation(batch.B)                             # graphcnn.py:199
+        if X is None:
+            X = batch.arena.features(batch)
+        c_logit, d_logit, g_f = self._run(batch, X, perm, want_disc=True)
+        if latent:
+            return g_f.detach().cpu().numpy()                                  # graphcnn.py:248-249
+        return c_logit, d_logit
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, batch_graph, latent=False):
+        if self.neighbor_pooling_type == "max":
+            return self._forward_max(batch_graph, latent)
+        batch = self.arena().batch(batch_graph)
+        return self.forward_batch(batch, latent=latent)
+
+    def compute_saliency(self, batch_graph, cls):
+        self.eval()
+        self.zero_grad()
+        assert len(batch_graph) == 1                                           # graphcnn.py:257
+        if self.neighbor_pooling_type == "max":
+            return self._saliency_max(batch_graph, cls)
+        batch = self.arena().batch(batch_graph)
+        X = batch.arena.features(batch).detach().requires_grad_()
+        score, _, _ = self._run(batch, X, np.zeros(1, dtype=np.int64), want_disc=False)
+        predicting_class = torch.zeros([1, 2], device=X.device)                # two classes hard-coded (:263)
+        predicting_class[0, cls] = 1
+        score.backward(predicting_class)
+        return X.grad
+
+    # ------------------------------------------------------------------ "max" fallback (plain torch)
+    def _padded_neighbors(self, batch_graph):
+        """graphcnn.py:55-81: padded neighbour list with -1 as the dummy slot."""
+        max_deg = max(g.max_neighbor for g in batch_graph)
+        rows, start = [], 0
+        for g in batch_graph:
+            for j, nb in enumerate(g.neighbors):
+                pad = [x + start for x in nb] + [-1] * (max_deg - len(nb))
+                if not self.learn_eps:
+                    pad.append(j + start)
+                rows.append(pad)
+            start += len(g.g)
+        return torch.LongTensor(rows)
+
+    def _encode_max(self, batch_graph, X):
+        dev = X.device
+        nbr = self._padded_neighbors(batch_graph).to(dev)
+        h, hidden = X, []
+        for l in range(self.num_layers):
+            dummy = torch.min(h, dim=0)[0]                                     # graphcnn.py:137-143
+            pooled = torch.max(torch.cat([h, dummy.reshape(1, -1)])[nbr], dim=1)[0]
+            if self.learn_eps:
+                pooled = pooled + (1 + self.eps[l]) * h
+            h = F.relu(self.batch_norms[l](self.mlps[l](pooled)))
+            hidden.append(h)
+        return hidden
+
+    def _readout_matrix(self, batch_graph, dev):
+        sizes = torch.tensor([len(g.g) for g in batch_graph])
+        seg = torch.repeat_interleave(torch.arange(len(batch_graph)), sizes)
+        val = torch.ones(int(sizes.sum()))
+        if self.graph_pooling_type == "average":
+            val = val / sizes[seg].float()
+        P = torch.zeros(len(batch_graph), int(sizes.sum()))
+        P[seg, torch.arange(int(sizes.sum()))] = val
+        return P.to(dev)
+
+    def _forward_max(self, batch_graph, latent):
+        dev = self.eps.device
+        X = torch.cat([g.node_features for g in batch_graph], 0).to(dev)
+        P = self._readout_matrix(batch_graph, dev)
+        perm = np.random.permutation(len(batch_graph))
+        idx = np.repeat(perm, len(batch_graph[0].node_features))
+        hidden = self._encode_max(batch_graph, X)
+        c_logit, pooled = 0, []
+        for l, h in enumerate(hidden):
+            ph = P @ h
+            c_logit = c_logit + F.dropout(self.linears_prediction[l](ph), self.final_dropout, training=self.training)
+            pooled.append(ph)
+        n_f, g_f = torch.cat(hidden, 1), torch.cat(pooled, 1)
+        d_logit = self.disc(self.sigm(g_f), n_f, n_f[idx, :], None, None)
+        if latent:
+            return g_f.detach().cpu().numpy()
+        return c_logit, d_logit
+
+    def _saliency_max(self, batch_graph, cls):
+        dev = self.eps.device
+        X = torch.cat([g.node_features for g in batch_graph], 0).to(dev).requires_grad_()
+        P = self._readout_matrix(batch_graph, dev)
+        score = 0
+        for l, h in enumerate(self._encode_max(batch_graph, X)):
+            score = score + self.linears_prediction[l](P @ h)
+        onehot = torch.zeros([1, 2], device=dev)
+        onehot[0, cls] = 1
+        score.backward(onehot)
+        return X.grad
+
+
+GraphCNN = GIN_InfoMaxReg  # the name BASELINE.json's north_star uses

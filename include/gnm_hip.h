@@ -1,0 +1,131 @@
+/* gnm_hip.h -- C-ABI of libgnm_hip.so: the MI355X (gfx950) GIN message-passing hot path.
+ *
+ * Drop-in boundary for the hot path of egyptdj/graph-neural-mapping
+ * (GIN_InfoMaxReg.forward / backward, /root/reference models/graphcnn.py:194-251).
+ * The reference is pure Python on PyTorch; it has no FFI of its own, so each entry
+ * point below names the reference call site (file:line) whose ATen work it replaces.
+ * The Python host mirror (graph-neural-mapping_amd/models/graphcnn.py) binds these
+ * through ctypes; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - matrices are fp32 row-major with an explicit leading dimension (in floats);
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises, allocates or
+ *     keeps global state (hipGraph-capturable);
+ *   - return value: 0 on success, >0 a hipError_t, <0 GNM_ERR_* below.
+ *
+ * Batch description (replaces the int64 block-diagonal COO built per forward at
+ * graphcnn.py:84-106 and the [B,N] readout COO at :109-134):
+ *   rowptr / col      per-graph CSR arena: int32 row offsets (n_g + 1 per graph,
+ *                     graph-local, starting at 0) and uint16 graph-local column ids;
+ *   b_rp_off[b]       offset (elements) of batch graph b's rowptr block in `rowptr`;
+ *   b_col_off[b]      offset of its column block in `col`;
+ *   node_off[B+1]     first node row of each batch graph in the concatenated [N, F]
+ *                     feature matrix (cumsum of len(graph.g), graphcnn.py:88-90).
+ */
+#ifndef GNM_HIP_H
+#define GNM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNM_OK 0
+#define GNM_ERR_BAD_ARG (-1)
+#define GNM_ERR_UNSUPPORTED (-2)
+
+const char* gnm_version(void);
+
+/* ---- host helpers (no GPU needed) ------------------------------------------------ */
+
+/* CSR of one graph from the reference's edge_mat ([2,E] int64 host array, row-major:
+ * sources then targets; util.py:99-103).  Stable in edge order, duplicates kept.
+ * Replaces the per-forward COO assembly at graphcnn.py:89-93. */
+int gnm_csr_from_edge_mat(const int64_t* edge_mat_host, long long E, int n, int32_t* rowptr_host,
+                          uint16_t* col_host);
+int gnm_csr_transpose(const int32_t* rowptr_host, const uint16_t* col_host, int n, int32_t* rowptr_t_host,
+                      uint16_t* col_t_host);
+int gnm_csr_is_symmetric(const int32_t* rowptr_host, const uint16_t* col_host, int n);
+/* Inverse of the above for a whole batch: the reference's Adj_block._indices()
+ * (graphcnn.py:91-104), rows grouped by (graph, row).  Used by the parity tests. */
+long long gnm_batch_coo_from_csr(const int32_t* rowptr_arena_host, const uint16_t* col_arena_host,
+                                 const int64_t* b_rp_off_host, const int64_t* b_col_off_host,
+                                 const int32_t* node_off_host, int B, int self_loops, int64_t* out_rows_host,
+                                 int64_t* out_cols_host);
+
+/* ---- neighbour aggregation --------------------------------------------------------
+ * forward  (backward = 0): y = A x [/ deg] + (1 + eps) x      learn_eps  (graphcnn.py:154-161)
+ *                          y = (A + I) x [/ (deg + 1)]        otherwise  (graphcnn.py:178-182, :97-102)
+ * backward (backward = 1): the autograd transpose of the above over the TRANSPOSED CSR
+ *                          (pass the forward CSR as deg_rowptr/b_deg_off; they may alias
+ *                          rowptr/b_rp_off for symmetric graphs), plus, when deps_partial
+ *                          is non-null, fp64 partials of d eps = sum(x * hfwd).
+ * `eps` points at eps[layer] on the device (null: coefficient 1).  `self_loop` = !learn_eps.
+ * n_max = largest graph of the batch.  Replaces torch.spmm at graphcnn.py:154,157,178,181. */
+int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
+            const int32_t* deg_rowptr, const int64_t* b_deg_off, const int32_t* node_off, int B, int n_max,
+            const float* x, int ldx, float* y, int ldy, int F, const float* eps, int average, int self_loop,
+            int backward, const float* hfwd, int ldh, double* deps_partial, void* stream);
+int gnm_agg_slice_width(int F, int n_max);          /* feature-slice width the kernel will use (0: unsupported) */
+int gnm_agg_num_partials(int F, int n_max, int B);  /* doubles written to deps_partial */
+int gnm_sum_partials(const double* partial, int count, float* out, void* stream);
+
+/* ---- Linear (mlp.py:25,32-35,43,48,49) on fp32 MFMA ---------------------------------
+ * Z[N,H] = f(X)[N,K] W^T + bias with f(x) = x*pro_scale + pro_shift (then ReLU if
+ * pro_relu) fused on load -- the BatchNorm+ReLU between two Linears (mlp.py:48).
+ * w_kmajor = 0: W is torch's [H,K] weight;  1: W is [K,H] (used for dX = dZ W).
+ * stats_partial (optional): [gnm_linear_grid(N)][2][H] doubles, per-column sum and sum
+ * of squares of Z for the BatchNorm that follows.  H <= 128 per call. */
+int gnm_linear_grid(int N);
+int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, int w_kmajor, const float* bias, float* Z,
+                   int ldz, int N, int K, int H, const float* pro_scale, const float* pro_shift, int pro_relu,
+                   double* stats_partial, void* stream);
+/* dW[H,K] = dZ^T f(X), db[H] = column sums of dZ (autograd of nn.Linear). */
+int gnm_wgrad_grid(int N);
+long long gnm_wgrad_workspace_floats(int N, int H, int K);
+int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ldx, int N, int H, int K,
+                     const float* pro_scale, const float* pro_shift, int pro_relu, float* dW, int ldw, float* db,
+                     float* workspace, void* stream);
+
+/* ---- BatchNorm1d + ReLU + readout (mlp.py:38,48; graphcnn.py:51,163-166,187-190,228-229) */
+int gnm_bn_finalize(const double* stats_partial, int nblk, int H, long long nrows, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float momentum, float eps, int training, int update_running, float* scale, float* shift,
+                    float* mean_out, float* rstd_out, void* stream);
+/* Hout = relu(Z*scale+shift); pooled[b] = sum (or mean) of graph b's rows (may be null). */
+int gnm_bn_relu_readout(const float* Z, int ldz, const float* scale, const float* shift, float* Hout, int ldh,
+                        const int32_t* node_off, int B, int H, int relu, float* pooled, int ldp, int average,
+                        void* stream);
+/* Backward pass 1: G = (dH + readout grad + discriminator grads) * relu mask, and the
+ * per-graph (sum G, sum G*xhat) partials [B][2][H]. */
+int gnm_bn_relu_bwd_stats(const float* dH, int lddh, const float* dpool, int ldp, int average, const float* dsc1,
+                          const float* U, int ldu, const int32_t* inv_perm, const float* s2sum, const float* Z,
+                          int ldz, const float* scale, const float* shift, const float* mean, const float* rstd,
+                          int relu, float* G, int ldg, const int32_t* node_off, int B, int H, double* partial,
+                          void* stream);
+int gnm_bn_bwd_finalize(const double* partial, int nblk, int H, long long nrows, const float* gamma,
+                        const float* rstd, int training, float* dgamma, float* dbeta, float* cA, float* m1,
+                        float* m2, void* stream);
+/* Backward pass 2: dZ = cA * (G - m1 - xhat*m2); dZ may alias G. */
+int gnm_bn_bwd_apply(const float* G, int ldg, const float* Z, int ldz, const float* mean, const float* rstd,
+                     const float* cA, const float* m1, const float* m2, float* dZ, int ldd, long long N, int H,
+                     void* stream);
+
+/* ---- Infomax discriminator (discriminator.py:19-38, graphcnn.py:233-246) ------------
+ * hptrs_host: HOST array of L device pointers to the per-layer [N,H] hidden states
+ * (n_f is never concatenated).  U = sigmoid(g_f) W^T, [B, L*H].  perm_rows[g] =
+ * perm[g], the ROW of n_f the reference's shuffle index selects for graph g.
+ * d_logit: [2N] (= the reference's [2N,1]). */
+int gnm_disc_score_fwd(const float* const* hptrs_host, int ldh, int L, int H, const float* U, int ldu,
+                       const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
+                       float* d_logit, void* stream);
+int gnm_disc_score_bwd(const float* const* hptrs_host, int ldh, int L, int H, const float* dD,
+                       const int32_t* perm_rows, const int32_t* node_off, int N, int B, float* dU, int ldu,
+                       float* s2sum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNM_HIP_H */

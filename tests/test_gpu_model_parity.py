@@ -1,0 +1,288 @@
+"""GPU parity of the whole hot path (GIN_InfoMaxReg over libgnm_hip.so) against
+(a) the golden vectors captured from the real reference and (b) the fp64 oracle.
+
+Tolerances: integer structures bit-exact; activations / logits <= 1e-5 relative
+(max-norm) -- the north_star bar; gradients 5e-5 (tiny cases).  The true-shape case uses
+the calibrated bounds documented in helpers.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (RTOL, TRUE_SHAPE_GRAD_RTOL, Calibrated, assert_close, edge_mat_of, golden_cases, grad_floor,
+                     load_case)
+
+pytestmark = pytest.mark.gpu
+CASES = golden_cases()
+DEV = "cuda:0"
+
+
+class G:
+    pass
+
+
+def make_graphs(cfg, d):
+    out = []
+    for g in range(cfg["B"]):
+        o = G()
+        o.g = list(range(cfg["n"]))
+        o.edge_mat = torch.from_numpy(edge_mat_of(d[f"und_{g}"]))
+        o.node_features = torch.from_numpy(d[f"feat_{g}"])
+        o.label = int(d["labels"][g])
+        o.neighbors = None
+        o.max_neighbor = 0
+        out.append(o)
+    return out
+
+
+def make_model(cfg, state, dropout=0.0):
+    from models.graphcnn import GIN_InfoMaxReg
+    dev = torch.device(DEV)
+    m = GIN_InfoMaxReg(cfg["L"], cfg["m"], cfg["f0"], cfg["H"], cfg["C"], dropout, cfg["learn_eps"], cfg["gpool"],
+                       cfg["npool"], dev)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+    return m.to(dev)
+
+
+def oracle_model(cfg, state):
+    from oracle import gin_oracle as O
+    return O, O.OracleGIN(state, cfg["L"], cfg["m"], cfg["learn_eps"], cfg["gpool"], cfg["npool"], dtype=np.float64)
+
+
+def oracle_batch(O, cfg, d):
+    return [O.OGraph(cfg["n"], edge_mat_of(d[f"und_{g}"]), d[f"feat_{g}"], int(d["labels"][g]))
+            for g in range(cfg["B"])]
+
+
+def capture_layers(model):
+    """pooled (input of the MLP) and hidden (layer output) of every layer, from the
+    tensors the autograd Function saved."""
+    from gnm import core
+    store = {}
+    orig = core.encoder_forward
+
+    def wrapped(*a, **k):
+        hidden, g_f, saved = orig(*a, **k)
+        store["hidden"] = [h.detach().cpu().numpy() for h in hidden]
+        store["pooled"] = [s[1].detach().cpu().numpy() for s in saved]
+        return hidden, g_f, saved
+
+    return store, orig, wrapped
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_index_structures_bit_exact(case):
+    """The device CSR arena encodes exactly the reference's Adj_block edge multiset and
+    offsets (graphcnn.py:84-106) and the readout segments (graphcnn.py:109-134)."""
+    cfg, state, d = load_case(case)
+    model = make_model(cfg, state)
+    graphs = make_graphs(cfg, d)
+    batch = model.arena().batch(graphs)
+    coo = model.arena().export_adj_coo(batch, self_loops=not cfg["learn_eps"])
+    ref = d["adj_indices"]
+    assert coo.dtype == np.int64 and coo.shape == ref.shape
+    canon = lambda a: a[:, np.lexsort((a[1], a[0]))]
+    assert np.array_equal(canon(coo), canon(ref))
+    # readout segments: graph_pool row i covers columns node_off[i]..node_off[i+1]
+    gp = d["gp_indices"]
+    node_off = batch.node_off.cpu().numpy()
+    seg = np.repeat(np.arange(cfg["B"]), np.diff(node_off))
+    assert np.array_equal(gp[0], seg) and np.array_equal(gp[1], np.arange(batch.N))
+    if cfg["gpool"] == "average":
+        w = (np.float32(1.0) / np.diff(node_off).astype(np.float32))[seg]
+        assert np.array_equal(w, d["gp_values"])
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_eval_forward_vs_golden(case):
+    from gnm import core
+    cfg, state, d = load_case(case)
+    model = make_model(cfg, state).eval()
+    graphs = make_graphs(cfg, d)
+    store, orig, wrapped = capture_layers(model)
+    core.encoder_forward = wrapped
+    try:
+        np.random.seed(cfg["np_seed"])
+        with torch.no_grad():
+            c_logit, d_logit = model(graphs)
+    finally:
+        core.encoder_forward = orig
+    rs = slice(None, None, cfg["row_stride"])
+    tol = RTOL if not case.startswith("true_") else 4 * RTOL   # see helpers.TRUE_SHAPE_FACTOR
+    for l in range(cfg["L"]):
+        assert_close(store["pooled"][l][rs], d[f"eval_pooled_{l}"], rtol=tol, what=f"pooled {l}")
+        assert_close(store["hidden"][l][rs], d[f"eval_hidden_{l}"], rtol=tol, what=f"hidden {l}")
+    assert_close(c_logit.cpu().numpy(), d["eval_c_logit"], rtol=tol, what="c_logit")
+    assert_close(d_logit.cpu().numpy(), d["eval_d_logit"], rtol=tol, what="d_logit")
+    np.random.seed(cfg["np_seed"])
+    lat = model(graphs, latent=True)
+    assert isinstance(lat, np.ndarray)
+    assert_close(lat, d["eval_latent"], rtol=tol, what="latent")
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_train_step_vs_golden_and_oracle(case):
+    from gnm import core
+    cfg, state, d = load_case(case)
+    model = make_model(cfg, state).train()
+    graphs = make_graphs(cfg, d)
+    store, orig, wrapped = capture_layers(model)
+    core.encoder_forward = wrapped
+    try:
+        np.random.seed(cfg["np_seed"])
+        c_logit, d_logit = model(graphs)
+    finally:
+        core.encoder_forward = orig
+    N = cfg["B"] * cfg["n"]
+    dev = c_logit.device
+    c_labels = torch.from_numpy(d["labels"]).to(dev)
+    d_labels = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev)      # main.py:32 sized by node count
+    c_loss = torch.nn.CrossEntropyLoss()(c_logit, c_labels)
+    d_loss = torch.nn.BCEWithLogitsLoss()(d_logit, d_labels)
+    loss = c_loss + 0.05 * d_loss
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+
+    O, om = oracle_model(cfg, state)
+    truth = om.train_step_grads(oracle_batch(O, cfg, d), d["perm"], beta=0.05)
+    tc = truth["cache"]
+    rs = slice(None, None, cfg["row_stride"])
+    true_shape = case.startswith("true_")
+    cal = Calibrated()
+    losses = np.array([loss.item(), c_loss.item(), d_loss.item()])
+    tl = np.array([truth["loss"], truth["c_loss"], truth["d_loss"]])
+    if true_shape:
+        for l in range(cfg["L"]):
+            cal.check(store["pooled"][l][rs], d[f"train_pooled_{l}"], tc["layers"][l]["pooled"][rs], what=f"pooled {l}")
+            cal.check(store["hidden"][l][rs], d[f"train_hidden_{l}"], tc["hidden"][l][rs], what=f"hidden {l}")
+        cal.check(c_logit.detach().cpu().numpy(), d["train_c_logit"], truth["c_logit"], what="c_logit")
+        cal.check(d_logit.detach().cpu().numpy(), d["train_d_logit"], truth["d_logit"], what="d_logit")
+        cal.check(losses, d["train_loss"], tl, what="loss")
+    else:
+        for l in range(cfg["L"]):
+            assert_close(store["pooled"][l], d[f"train_pooled_{l}"], what=f"pooled {l} vs golden")
+            assert_close(store["hidden"][l], d[f"train_hidden_{l}"], what=f"hidden {l} vs golden")
+            assert_close(store["hidden"][l], tc["hidden"][l], what=f"hidden {l} vs fp64 oracle")
+        assert_close(c_logit.detach().cpu().numpy(), d["train_c_logit"], what="c_logit")
+        assert_close(d_logit.detach().cpu().numpy(), d["train_d_logit"], what="d_logit")
+        assert_close(losses, d["train_loss"], what="loss")
+
+    gtol = TRUE_SHAPE_GRAD_RTOL if true_shape else 5 * RTOL
+    floor = grad_floor(d)
+    checked = 0
+    for name, p in model.named_parameters():
+        key = "grad_" + name
+        if f"gradnone_{name}" in d:
+            assert p.grad is None, name
+            continue
+        g = p.grad.detach().cpu().numpy()
+        tg = truth["grads"][name].reshape(g.shape)
+        assert_close(g, tg, rtol=gtol, what=name + " vs fp64 oracle", floor=floor)
+        if key in d and not true_shape:
+            assert_close(g, d[key], rtol=gtol, what=name + " vs golden", floor=floor)
+        checked += 1
+    assert checked >= 10
+    for key in d:
+        if key.startswith("bufafter_"):
+            name = key[len("bufafter_"):]
+            got = dict(model.named_buffers())[name].cpu().numpy()
+            if name.endswith("num_batches_tracked"):
+                assert int(got) == int(d[key])
+            elif true_shape:
+                cal.check(got, d[key], om.p[name], what=key)
+            else:
+                assert_close(got, d[key], what=key)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c.startswith("tiny_")])
+def test_saliency_vs_golden(case):
+    cfg, state, d = load_case(case)
+    model = make_model(cfg, state)
+    graphs = make_graphs(cfg, d)
+    for cls in (0, 1):
+        sal = model.compute_saliency([graphs[0]], cls)
+        assert sal.shape == (cfg["n"], cfg["f0"])
+        assert_close(sal.cpu().numpy(), d[f"saliency_cls{cls}"], rtol=5 * RTOL, what=f"saliency {cls}")
+    assert not model.training            # compute_saliency leaves the model in eval mode (graphcnn.py:255)
+
+
+def test_dropout_train_mode_runs_and_scales():
+    """final_dropout > 0 in train mode: logits are a masked/scaled sum (graphcnn.py:230)."""
+    cfg, state, d = load_case("tiny_s0_eps1_gsum_nsum")
+    model = make_model(cfg, state, dropout=0.5).train()
+    graphs = make_graphs(cfg, d)
+    torch.manual_seed(0)
+    np.random.seed(1)
+    c1, _ = model(graphs)
+    model2 = make_model(cfg, state, dropout=0.0).train()
+    np.random.seed(1)
+    c0, _ = model2(graphs)
+    assert c1.shape == c0.shape and torch.isfinite(c1).all()
+    assert not torch.allclose(c1, c0)
+
+
+def test_isolated_node_average_nan_matches_reference():
+    """graphcnn.py:157-158: 0/0 for an isolated node under average pooling + learn_eps."""
+    from gnm import core
+    cfg, state, d = load_case("tiny_s1_eps1_gsum_naverage")
+    model = make_model(cfg, state).eval()
+    graphs = make_graphs(cfg, d)[:1]
+    em = graphs[0].edge_mat.numpy()
+    keep = (em[0] != 3) & (em[1] != 3)
+    graphs[0].edge_mat = torch.from_numpy(np.ascontiguousarray(em[:, keep]))
+    store, orig, wrapped = capture_layers(model)
+    core.encoder_forward = wrapped
+    try:
+        with torch.no_grad():
+            model(graphs)
+    finally:
+        core.encoder_forward = orig
+    assert np.isnan(store["pooled"][0][3]).all()
+    assert not np.isnan(store["pooled"][0][0]).any()
+
+
+def test_non_symmetric_graph_backward_uses_transposed_csr():
+    """Reference graphs are symmetric (util.py:99-100) but edge_mat may be anything:
+    gradients must follow A^T.  Checked against the fp64 oracle."""
+    cfg, state, d = load_case("tiny_s1_eps1_gsum_nsum")
+    rng = np.random.default_rng(5)
+    graphs = make_graphs(cfg, d)
+    O, om = oracle_model(cfg, state)
+    ob = []
+    for g in graphs:
+        em = g.edge_mat.numpy()
+        em = em[:, rng.random(em.shape[1]) < 0.6]          # drop edges at random -> asymmetric
+        g.edge_mat = torch.from_numpy(np.ascontiguousarray(em))
+        ob.append(O.OGraph(cfg["n"], em, g.node_features.numpy(), g.label))
+    model = make_model(cfg, state).train()
+    np.random.seed(3)
+    perm = np.random.permutation(cfg["B"])
+    np.random.seed(3)
+    c_logit, d_logit = model(graphs)
+    assert not model.arena().batch(graphs).symmetric
+    truth = om.train_step_grads(ob, perm)
+    N = cfg["B"] * cfg["n"]
+    dev = c_logit.device
+    loss = torch.nn.CrossEntropyLoss()(c_logit, torch.from_numpy(d["labels"]).to(dev)) + 0.05 * \
+        torch.nn.BCEWithLogitsLoss()(d_logit, torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev))
+    loss.backward()
+    assert_close(c_logit.detach().cpu().numpy(), truth["c_logit"], what="c_logit")
+    floor = 2e-2 * max(float(np.abs(v).max()) for v in truth["grads"].values())
+    for name, p in model.named_parameters():
+        assert_close(p.grad.cpu().numpy(), truth["grads"][name].reshape(p.shape), rtol=5 * RTOL, what=name,
+                     floor=floor)
+
+
+def test_run_to_run_determinism():
+    """All reductions are fixed-order: two identical steps give bitwise identical grads."""
+    cfg, state, d = load_case("true_s0_eps1_gsum_nsum")
+    graphs = make_graphs(cfg, d)
+    outs = []
+    for _ in range(2):
+        model = make_model(cfg, state).train()
+        np.random.seed(11)
+        c_logit, d_logit = model(graphs)
+        (c_logit.sum() + d_logit.sum()).backward()
+        outs.append([p.grad.clone() for p in model.parameters() if p.grad is not None] + [c_logit.detach(), d_logit.detach()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
