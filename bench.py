@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: graphs/sec, forward + backward, of the GIN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload at N = 1 (BASELINE.json configs[1]): batches of 1024 synthetic 400-node dense-FC
+connectivity graphs (47,600 directed edges each), 7 input features, hidden 64, 5 GIN
+layers, 2-layer MLPs, sum/sum pooling, learn_eps, train mode, final_dropout 0.5.  One step
+= one full GIN_InfoMaxReg.forward (encoder + readout + classifier + Infomax
+discriminator) + the reference loss CE + 0.05*BCE (main.py:34-37) + backward; the graph
+pool (CSR + features) and labels are resident in HBM before the timed region.  For N > 1
+every rank owns `--batch` graphs per step (weak scaling, configs[2] at --batch 512) and the
+step ends with ONE RCCL all-reduce of the flat gradient buffer.
+
+Prints one JSON line (rank 0).  Extra objects:
+  roofline      the sum-aggregation kernel at F = 64 (forward launches): algorithmic bytes
+                (396,804 B per graph-layer) / mean launch duration from
+                HIP events on the launch stream, against 8 TB/s.
+  roofline_mlp  the fp32-MFMA Linear(64,64) forward launches against 157.3 TFLOP/s.
+  cpu_baseline  oracle/gin_oracle.py (numpy/scipy port of the reference's CPU path,
+                pinned to the reference's golden vectors) timed on this host on config
+                C1 (B = 32 of the same graphs), rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "graph-neural-mapping_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+AGG_BYTES_PER_GRAPH_LAYER = lambda n, E, Fw: 4 * n * Fw * 2 + 4 * E + 4 * (n + 1)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_MEASURED_GBS = 6290.0
+MFMA_F32_PEAK_TF = 157.3
+
+
+def cpu_baseline(graphs, state, budget_s=20.0):
+    """The oracle (kind 'port') on config C1: 32 graphs, fwd + loss + bwd, fp32."""
+    from oracle import gin_oracle as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    ob = [O.OGraph(len(g.g), g.edge_mat.numpy(), g.node_features.numpy(), g.label) for g in graphs]
+    model = O.OracleGIN(state, 5, 2, True, "sum", "sum", dtype=np.float32)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(ob))
+    model.train_step_grads(ob, perm, update_running=False)          # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
+        t0 = time.perf_counter()
+        model.train_step_grads(ob, perm, update_running=False)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    cpu = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": len(ob) / med, "unit": "graphs/s", "cores": int(threads), "kind": "port",
+            "sample": "config C1: %d dense-FC 400-node graphs, fwd+loss+bwd, fp32 numpy/scipy oracle, median of %d "
+                      "steps (%.2f s each)" % (len(ob), len(times), med),
+            "host_cpu": cpu, "host_logical_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="graphs per GPU per step (default 1024; 512 when --gpus > 1)")
+    ap.add_argument("--pool", type=int, default=None, help="distinct graphs resident per GPU (default = batch)")
+    ap.add_argument("--hidden", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py ..."
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gnm import core, synth
+    from gnm.parallel import DataParallelGIN, seed_rank_rng
+    from models.graphcnn import GIN_InfoMaxReg
+
+    B = args.batch or (1024 if world == 1 else 512)
+    pool_n = args.pool or B
+    n, f0, H, L, C = 400, 7, args.hidden, args.layers, 2
+
+    t_gen = time.perf_counter()
+    pool = synth.make_pool("dense_fc", pool_n, first=rank * pool_n, n=n, f0=f0)
+    torch.manual_seed(0)
+    model = GIN_InfoMaxReg(L, 2, f0, H, C, 0.5, True, "sum", "sum", dev).to(dev)
+    state_cpu = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    model.train()
+    dp = DataParallelGIN(model)
+    dp.broadcast_parameters()
+    arena = model.arena()
+    gids_all = np.array([arena.add(g) for g in pool], dtype=np.int64)
+    labels_all = torch.tensor([g.label for g in pool], dtype=torch.int64, device=dev)
+    E = int(pool[0].edge_mat.shape[1])
+    t_gen = time.perf_counter() - t_gen
+
+    rng = np.random.default_rng(1234 + rank)
+    seed_rank_rng(99, rank)
+    nsteps = args.warmup + args.steps
+    batches = []
+    for _ in range(nsteps):
+        sel = rng.permutation(pool_n)[:B] if pool_n >= B else rng.integers(0, pool_n, B)
+        bt = arena.batch_from_gids(gids_all[sel])
+        batches.append((bt, labels_all[torch.as_tensor(sel, device=dev)]))
+    N = batches[0][0].N
+    d_labels = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev)   # main.py:32, sized by node count
+
+    def step(i):
+        bt, lab = batches[i]
+        dp.zero_grad()
+        c_logit, d_logit = model.forward_batch(bt)
+        loss = F.cross_entropy(c_logit, lab) + 0.05 * F.binary_cross_entropy_with_logits(d_logit, d_labels)
+        loss.backward()
+        dp.allreduce_gradients()
+        return loss
+
+    for i in range(args.warmup):
+        step(i)
+    if not args.no_kernel_timer:
+        core.TIMER = core.KernelTimer()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nsteps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer, core.TIMER = core.TIMER, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss.item())
+    if not np.isfinite(loss_val):
+        raise SystemExit("non-finite loss %r" % loss_val)
+
+    if rank == 0:
+        total_graphs = B * world * args.steps
+        out = {
+            "metric": "graphs/sec fwd+bwd, 400-node dense FC graphs, hidden_dim 64, 5 layers",
+            "value": total_graphs / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[%d]: %d x %d dense-FC 400-node graphs/step (47,600 directed edges each), "
+                                   "F0=7, hidden %d, %d GIN layers, 2-layer MLP, sum/sum, learn_eps, "
+                                   "full forward (classifier + Infomax discriminator) + CE+0.05*BCE + backward%s"
+                                   % (1 if world == 1 else 2, world, B, H, L,
+                                      ", flat-gradient RCCL all-reduce" if world > 1 else ""),
+                       "graphs_per_gpu": B, "global_batch": B * world, "nodes_per_graph": n, "edges_per_graph": E,
+                       "pool_graphs_per_gpu": pool_n, "parallelism": "dp%d" % world},
+            "final_loss": loss_val, "setup_seconds": round(t_gen, 1),
+        }
+        roof, roof_mlp = None, None
+        if timer is not None:
+            summ = timer.summary()
+            out["kernel_ms"] = {k: [c, round(ms, 4)] for k, (c, ms, _) in sorted(summ.items())}
+            key = "agg_fwd_F%d" % H
+            if key in summ:
+                c, ms, meta = summ[key]
+                bytes_launch = AGG_BYTES_PER_GRAPH_LAYER(n, E, H) * meta["B"]
+                ach = bytes_launch / (ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": "gnm_agg_kernel<16> (forward, F=%d)" % H, "achieved": ach,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "frac_of_measured_copy_peak": ach / HBM_MEASURED_GBS, "traffic": None,
+                        "algorithmic_bytes_per_launch": bytes_launch, "mean_launch_ms": ms, "launches_timed": c,
+                        "graph_layers_per_s": meta["B"] / (ms * 1e-3)}
+            key = "lin_fwd_K%d_H%d" % (H, H)
+            if key in summ:
+                c, ms, meta = summ[key]
+                fl = 2.0 * meta["N"] * H * H
+                tf = fl / (ms * 1e-3) / 1e12
+                roof_mlp = {"bound": "mfma", "kernel": "gnm_lin_kernel<64,2> (Linear %dx%d fwd)" % (H, H),
+                            "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                            "mean_launch_ms": ms, "launches_timed": c,
+                            "hbm_GBs": (meta["N"] * H * 4 * 2) / (ms * 1e-3) / 1e9}
+        out["roofline"] = roof
+        out["roofline_mlp"] = roof_mlp
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pool[:32], state_cpu)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,14 @@ def _load():
         raise GnmError(
             "libgnm_hip.so not found at %s -- build it first (python __graft_entry__.py, or "
             "python graph-neural-mapping_amd/gnm/_build.py).  There is no CPU fallback." % path)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME
+    # as /opt/rocm's).  Load torch's copy FIRST so the dynamic loader resolves this
+    # library's DT_NEEDED libamdhip64.so.7 to it; otherwise streams and device pointers
+    # would cross two independent runtimes (hipErrorNoDevice / invalid handle).
+    import torch
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(tl):
+        C.CDLL(tl, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing

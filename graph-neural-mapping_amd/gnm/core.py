@@ -26,6 +26,43 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels are
+    launched on (torch's current stream).  bench.py turns it on for the timed region to
+    compute the roofline figures; it is off (None) otherwise."""
+
+    def __init__(self):
+        self.records = []          # (name, meta, start_event, end_event)
+
+    def summary(self):
+        """name -> (count, mean ms, meta of the first record); call after a synchronize."""
+        out = {}
+        for name, meta, a, b in self.records:
+            c, t, m = out.get(name, (0, 0.0, meta))
+            out[name] = (c + 1, t + a.elapsed_time(b), m)
+        return {k: (c, t / c, m) for k, (c, t, m) in out.items()}
+
+
+TIMER = None
+
+
+class _timed:
+    def __init__(self, name, **meta):
+        self.name, self.meta = name, meta
+
+    def __enter__(self):
+        if TIMER is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if TIMER is not None:
+            self.b.record()
+            TIMER.records.append((self.name, self.meta, self.a, self.b))
+        return False
+
+
 class GinSpec:
     """Static description of the model: which parameter tensor is which."""
 
@@ -43,17 +80,21 @@ def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None)
         rp_off, col_off = batch.t_rp_off, batch.t_col_off
     else:
         rp_off, col_off = batch.rp_off, batch.col_off
-    check(lib.gnm_agg(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), rp_off.data_ptr(), col_off.data_ptr(),
-                      a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), batch.B,
-                      batch.n_max, x.data_ptr(), x.stride(0), ptr(y), y.stride(0) if y is not None else 0, F_,
-                      eps_ptr, int(spec.n_avg), int(not spec.learn_eps), int(backward), ptr(hfwd),
-                      hfwd.stride(0) if hfwd is not None else 0, ptr(deps_partial), _stream()), "gnm_agg")
+    tag = "agg_%s_F%d%s" % ("bwd" if backward else "fwd", F_, "_dot" if y is None else "")
+    with _timed(tag, F=F_, B=batch.B, N=batch.N):
+        check(lib.gnm_agg(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), rp_off.data_ptr(), col_off.data_ptr(),
+                          a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), batch.B,
+                          batch.n_max, x.data_ptr(), x.stride(0), ptr(y), y.stride(0) if y is not None else 0, F_,
+                          eps_ptr, int(spec.n_avg), int(not spec.learn_eps), int(backward), ptr(hfwd),
+                          hfwd.stride(0) if hfwd is not None else 0, ptr(deps_partial), _stream()), "gnm_agg")
 
 
 def _linear(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
-    check(lib.gnm_linear_fwd(x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), int(w_kmajor), ptr(bias),
-                             z.data_ptr(), z.stride(0), N, K, H, ptr(pro[0]) if pro else None,
-                             ptr(pro[1]) if pro else None, 1 if pro else 0, ptr(stats), _stream()), "gnm_linear_fwd")
+    with _timed("lin_%s_K%d_H%d" % ("dgrad" if w_kmajor else "fwd", K, H), N=N, K=K, H=H):
+        check(lib.gnm_linear_fwd(x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), int(w_kmajor), ptr(bias),
+                                 z.data_ptr(), z.stride(0), N, K, H, ptr(pro[0]) if pro else None,
+                                 ptr(pro[1]) if pro else None, 1 if pro else 0, ptr(stats), _stream()),
+              "gnm_linear_fwd")
 
 
 def _linear_wide(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
@@ -266,10 +307,12 @@ class GinInfoMaxFn(torch.autograd.Function):
                 dW = torch.empty_like(W)
                 db = torch.empty(Hk, **f32)
                 ws = torch.empty(int(lib.gnm_wgrad_workspace_floats(N, Hk, K)), **f32)
-                check(lib.gnm_linear_wgrad(dZ.data_ptr(), dZ.stride(0), sv.x_in.data_ptr(), sv.x_in.stride(0), N, Hk,
-                                           K, ptr(sv.pro[0]) if sv.pro else None, ptr(sv.pro[1]) if sv.pro else None,
-                                           1 if sv.pro else 0, dW.data_ptr(), dW.stride(0), db.data_ptr(),
-                                           ws.data_ptr(), st), "gnm_linear_wgrad")
+                with _timed("wgrad_K%d_H%d" % (K, Hk), N=N, K=K, H=Hk):
+                    check(lib.gnm_linear_wgrad(dZ.data_ptr(), dZ.stride(0), sv.x_in.data_ptr(), sv.x_in.stride(0), N,
+                                               Hk, K, ptr(sv.pro[0]) if sv.pro else None,
+                                               ptr(sv.pro[1]) if sv.pro else None, 1 if sv.pro else 0,
+                                               dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), st),
+                          "gnm_linear_wgrad")
                 grads[wname + ".weight"], grads[wname + ".bias"] = dW, db
                 # dX of this Linear: always for inner Linears; for the first one only when the
                 # aggregation backward below has a consumer (a lower layer, dX, or d eps[l])

@@ -1,0 +1,88 @@
+"""Data-parallel driver: one process per GPU, batch sharded by graph, ONE all-reduce of a
+flat fp32 gradient buffer per step (RCCL over xGMI when the backend is "nccl").
+
+The reference is single-process (main.py:126); this is the MI355X-native addition of
+SURVEY.md section 8(e).  A graph is never split: rank r owns graphs [r*B/W, (r+1)*B/W) of
+every global batch, no edge crosses ranks, so the only exchange step is the gradient
+sum.  The model has 142,288 parameters (569 KB) at H=64: the collective is latency-bound,
+so all gradients live in one contiguous buffer and a single call moves them.
+BatchNorm statistics are per rank (standard DDP semantics).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class FlatParams:
+    """Re-homes every parameter and its .grad as views of two flat fp32 buffers."""
+
+    def __init__(self, module):
+        params = [p for p in module.parameters()]
+        self.params = params
+        total = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view_as(p.data)
+            p.grad = self.flat_grad[off:off + n].view_as(p.data)
+            off += n
+        self.total = total
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        off = 0
+        for p in self.params:      # autograd may have replaced .grad; re-attach the views
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                p.grad = self.flat_grad[off:off + n].view_as(p.data)
+            off += n
+
+
+class DataParallelGIN:
+    """Wraps a GIN_InfoMaxReg replica.  broadcast_parameters() once, then per step:
+    zero_grad(); loss(forward(local shard)).backward(); allreduce_gradients()."""
+
+    def __init__(self, model, process_group=None):
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.fp = FlatParams(model)
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            dist.broadcast(self.fp.flat, src=src, group=self.group)
+            for b in self.model.buffers():
+                dist.broadcast(b, src=src, group=self.group)
+
+    def shard(self, global_items):
+        """This rank's contiguous slice of a global batch (list or index array)."""
+        B = len(global_items)
+        per = B // self.world
+        if per * self.world != B:
+            raise ValueError("global batch %d is not divisible by world size %d" % (B, self.world))
+        return global_items[self.rank * per:(self.rank + 1) * per]
+
+    def zero_grad(self):
+        self.fp.zero_grad()
+
+    def allreduce_gradients(self, async_op=False):
+        """Sum over ranks then scale by 1/W (the mean-loss convention of main.py:34-37
+        applied to the union batch)."""
+        if self.world == 1:
+            return None
+        work = dist.all_reduce(self.fp.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            return work
+        self.fp.flat_grad.div_(self.world)
+        return None
+
+
+def seed_rank_rng(base_seed, rank):
+    """Distinct numpy streams per rank: the Infomax negative-sampling permutation
+    (graphcnn.py:199) is drawn over the LOCAL batch."""
+    np.random.seed(base_seed + 7919 * rank)
