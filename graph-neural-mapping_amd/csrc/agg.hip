@@ -30,6 +30,7 @@
 //                    graphcnn.py:97-102)
 // In backward it also produces d eps[layer] = sum dpooled * h (fp64 partials).
 #include "gnm_common.h"
+#include <stdlib.h>
 
 struct AggArgs {
     const int32_t* rowptr;     // gather structure arena (forward CSR, or transposed for backward)
@@ -238,6 +239,329 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Specialised kernel for FS = 64 floats (LPR = 16, 256-B LDS rows): the headline shape
+// (hidden_dim 64).  Same math as gnm_agg_kernel<16>; what changes is the schedule:
+//   * phase A keeps 4 x 16 B (+ 4 x 16 B of hfwd) per thread in flight instead of one;
+//   * the graph's rowptr is staged in LDS so the per-row bounds are LDS reads
+//     (in order with the gather's ds_reads) instead of dependent scalar loads;
+//   * waves take GROUPS OF 4 consecutive destination rows from an LDS ticket counter
+//     (degree imbalance never idles a wave), and the column ids of the NEXT row are
+//     fetched (two 64-id chunks) while the current row is gathered, so the global
+//     index latency is off the critical path;
+//   * gather steps run in unguarded blocks of 4 (padding slots point at a zero row),
+//     so 4 ds_read_b128 are in flight before the first add waits;
+//   * the four quarter-wave partial sums of 4 rows are combined by a 2-step
+//     transposing butterfly (12 shuffles per 4 rows instead of 32), after which
+//     quarter q owns row q: the epilogue and the 1-KiB output store use all 64 lanes.
+// ---------------------------------------------------------------------------------
+#define GNM_GROUP4(G)                                                          \
+    {                                                                          \
+        const f32x4 t0_ = lds_read16(row_bcast16<4 * G + 0>(valb) + subb);     \
+        const f32x4 t1_ = lds_read16(row_bcast16<4 * G + 1>(valb) + subb);     \
+        const f32x4 t2_ = lds_read16(row_bcast16<4 * G + 2>(valb) + subb);     \
+        const f32x4 t3_ = lds_read16(row_bcast16<4 * G + 3>(valb) + subb);     \
+        acc4(acc, t0_); acc4(acc, t1_); acc4(acc, t2_); acc4(acc, t3_);        \
+    }
+
+#define GNM_RD(S) lds_read16(row_bcast16<S>(valb) + subb)
+#define GNM_BLOCK8(H)                                                                                   \
+    {                                                                                                   \
+        const f32x4 a0_ = GNM_RD(8 * H + 0), a1_ = GNM_RD(8 * H + 1), a2_ = GNM_RD(8 * H + 2),           \
+                    a3_ = GNM_RD(8 * H + 3), a4_ = GNM_RD(8 * H + 4), a5_ = GNM_RD(8 * H + 5),           \
+                    a6_ = GNM_RD(8 * H + 6), a7_ = GNM_RD(8 * H + 7);                                     \
+        acc4(acc, (a0_ + a1_) + (a2_ + a3_));                                                           \
+        acc4(acc, (a4_ + a5_) + (a6_ + a7_));                                                           \
+    }
+#define GNM_BLOCK16()                                                                                   \
+    {                                                                                                   \
+        const f32x4 a0_ = GNM_RD(0), a1_ = GNM_RD(1), a2_ = GNM_RD(2), a3_ = GNM_RD(3), a4_ = GNM_RD(4),  \
+                    a5_ = GNM_RD(5), a6_ = GNM_RD(6), a7_ = GNM_RD(7), a8_ = GNM_RD(8), a9_ = GNM_RD(9),  \
+                    a10_ = GNM_RD(10), a11_ = GNM_RD(11), a12_ = GNM_RD(12), a13_ = GNM_RD(13),           \
+                    a14_ = GNM_RD(14), a15_ = GNM_RD(15);                                                 \
+        acc4(acc, (a0_ + a1_) + (a2_ + a3_));                                                           \
+        acc4(acc, (a4_ + a5_) + (a6_ + a7_));                                                           \
+        acc4(acc, (a8_ + a9_) + (a10_ + a11_));                                                         \
+        acc4(acc, (a12_ + a13_) + (a14_ + a15_));                                                       \
+    }
+
+// x' + y' after v_permlane32_swap: lanes 0-31 get x[l] + x[l+32], lanes 32-63 get y[l-32] + y[l]
+__device__ __forceinline__ float swap_add32_1(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float4 swap_add32(const float4 x, const float4 y) {
+    return make_float4(swap_add32_1(x.x, y.x), swap_add32_1(x.y, y.y), swap_add32_1(x.z, y.z), swap_add32_1(x.w, y.w));
+}
+// after v_permlane16_swap: 16-lane rows 0,2 get x[row]+x[row+1], rows 1,3 get y[row-1]+y[row]
+__device__ __forceinline__ float swap_add16_1(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float4 swap_add16(const float4 x, const float4 y) {
+    return make_float4(swap_add16_1(x.x, y.x), swap_add16_1(x.y, y.y), swap_add16_1(x.z, y.z), swap_add16_1(x.w, y.w));
+}
+
+__device__ __forceinline__ float4 sel4(bool c, const float4 a, const float4 b) {
+    return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+__device__ __forceinline__ float4 shfl_xor4(const float4 v, int m) {
+    return make_float4(__shfl_xor(v.x, m, 64), __shfl_xor(v.y, m, 64), __shfl_xor(v.z, m, 64),
+                       __shfl_xor(v.w, m, 64));
+}
+
+__global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
+    constexpr int LPR = 16;
+    constexpr int FS = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* tile = reinterpret_cast<float4*>(smem);
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int b = blockIdx.x / p.nslices;
+    const int sl = blockIdx.x - b * p.nslices;
+    const int row0 = p.node_off[b];
+    const int n = p.node_off[b + 1] - row0;
+    const int col0 = sl * FS;
+    const int32_t* rp = p.rowptr + p.b_rp_off[b];
+    const uint16_t* cl = p.col + p.b_col_off[b];
+    const int32_t* drp = p.deg_rowptr + p.b_deg_off[b];
+    const int tid = threadIdx.x;
+    const int nthreads = blockDim.x;
+    int* rp_s = reinterpret_cast<int*>(smem + (size_t)(n + 1) * (FS * 4));   // [n + 1] row offsets
+    const bool vec_in = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    const bool vec_h = p.hfwd && ((p.ldh & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.hfwd) & 15) == 0);
+    const bool prescale = p.backward && p.average;
+    const int nwaves = nthreads >> 6;
+
+    // ---- phase A ---------------------------------------------------------------
+    for (int i = tid; i <= n; i += nthreads) rp_s[i] = rp[i];
+    double dot = 0.0;
+    const int total = n * LPR;
+    constexpr int UNR = 4;
+    const bool fast = vec_in && (col0 + FS <= p.F) && (!p.deps_partial || vec_h);
+    int base = tid;
+    if (fast) {
+        // branch-free main part: UNR x 16 B (+ UNR x 16 B of hfwd) per thread in flight
+        for (; base + (UNR - 1) * nthreads < total; base += nthreads * UNR) {
+            float4 v[UNR], hh[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = base + u * nthreads;
+                const size_t off = (size_t)(row0 + (i >> 4)) * p.ldx + col0 + 4 * (i & 15);
+                v[u] = *reinterpret_cast<const float4*>(p.x + off);
+            }
+            if (p.deps_partial) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int i = base + u * nthreads;
+                    const size_t off = (size_t)(row0 + (i >> 4)) * p.ldh + col0 + 4 * (i & 15);
+                    hh[u] = *reinterpret_cast<const float4*>(p.hfwd + off);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    dot += (double)v[u].x * hh[u].x + (double)v[u].y * hh[u].y + (double)v[u].z * hh[u].z +
+                           (double)v[u].w * hh[u].w;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = base + u * nthreads;
+                float4 w = v[u];
+                if (prescale) {
+                    const int r = i >> 4;
+                    const float d = (float)(drp[r + 1] - drp[r] + p.self_loop);
+                    w.x /= d; w.y /= d; w.z /= d; w.w /= d;
+                }
+                tile[i] = w;
+            }
+        }
+    }
+    for (; base < total; base += nthreads) {      // tail, and the generic (unaligned / partial-width) path
+        const int i = base;
+        const int r = i >> 4, c = i & 15;
+        const int cc = col0 + 4 * c;
+        const float* src = p.x + (size_t)(row0 + r) * p.ldx + cc;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec_in && cc + 3 < p.F) {
+            w = *reinterpret_cast<const float4*>(src);
+        } else {
+            if (cc + 0 < p.F) w.x = src[0];
+            if (cc + 1 < p.F) w.y = src[1];
+            if (cc + 2 < p.F) w.z = src[2];
+            if (cc + 3 < p.F) w.w = src[3];
+        }
+        if (p.deps_partial) {
+            const float* hs = p.hfwd + (size_t)(row0 + r) * p.ldh + cc;
+            float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vec_h && cc + 3 < p.F) {
+                h4 = *reinterpret_cast<const float4*>(hs);
+            } else {
+                if (cc + 0 < p.F) h4.x = hs[0];
+                if (cc + 1 < p.F) h4.y = hs[1];
+                if (cc + 2 < p.F) h4.z = hs[2];
+                if (cc + 3 < p.F) h4.w = hs[3];
+            }
+            dot += (double)w.x * h4.x + (double)w.y * h4.y + (double)w.z * h4.z + (double)w.w * h4.w;
+        }
+        if (prescale) {
+            const float d = (float)(drp[r + 1] - drp[r] + p.self_loop);
+            w.x /= d; w.y /= d; w.z /= d; w.w /= d;
+        }
+        tile[i] = w;
+    }
+    if (tid < LPR) tile[n * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    // ---- phase B ---------------------------------------------------------------
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane & 15;
+    const int q = lane >> 4;                                   // quarter of the wave
+    const unsigned subb = lds_base + (unsigned)sub * 16u;
+    const int jlane = sub * 4 + q;                             // edge of a 64-chunk this lane fetches
+    const unsigned zero_row_b = (unsigned)n * (FS * 4);
+    const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
+    const bool vec_out = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+    const int ngroups = p.y ? (n + 3) >> 2 : 0;
+
+    // Groups of 4 consecutive rows are dealt round-robin to the waves (group g -> wave g % nwaves).
+    // No LDS round trip sits on the per-row critical path: under load the LDS queue is ~1000
+    // cycles deep, so row bounds come from a lane vector loaded once per 8 groups
+    // (v_readlane), column ids are fetched one row ahead, and the 4-row combine below is
+    // pure VALU (v_permlane32_swap / v_permlane16_swap).
+    for (int k0 = 0; wave + k0 * nwaves < ngroups; k0 += 8) {
+        int rpv = 0;
+        {
+            const int gg = wave + (k0 + (lane >> 3)) * nwaves;
+            const int row = min(4 * gg + min(lane & 7, 4), n);
+            if (gg < ngroups) rpv = rp_s[row];
+        }
+        int ng = (ngroups - wave - k0 * nwaves + nwaves - 1) / nwaves;    // groups of this wave in this block
+        ng = min(ng, 8);
+        int nbeg = __builtin_amdgcn_readlane(rpv, 0), nend = __builtin_amdgcn_readlane(rpv, 1);
+        // Column ids are prefetched one row ahead as RAW values and only turned into LDS
+        // addresses when the row becomes current, so the wait is a counted vmcnt at the use.
+        // The loads are unconditional (the arena keeps >= 128 readable ids past the last
+        // block): a load inside a divergent branch would be drained (vmcnt(0)) at the join.
+        unsigned nra = cl[nbeg + jlane], nrb = cl[nbeg + 64 + jlane];
+        for (int kk = 0; kk < ng; ++kk) {
+            const int g = wave + (k0 + kk) * nwaves;
+            float4 racc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int beg = nbeg, end = nend;
+                const unsigned ra = nra, rb = nrb;
+                // issue the loads of the row after this one
+                const int tl = (r < 3) ? (8 * kk + r + 1) : (8 * (kk + 1));
+                if (r < 3 || kk + 1 < ng) {                   // wave-uniform
+                    nbeg = __builtin_amdgcn_readlane(rpv, tl);
+                    nend = __builtin_amdgcn_readlane(rpv, tl + 1);
+                } else {
+                    nend = nbeg;                               // nothing follows: an empty row at a valid address
+                }
+                nra = cl[nbeg + jlane];
+                nrb = cl[nbeg + 64 + jlane];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                int cnt = end - beg;
+                int e0 = beg;
+                const unsigned ia = (jlane < cnt) ? ra * (FS * 4) : zero_row_b;
+                const unsigned ib = (jlane + 64 < cnt) ? rb * (FS * 4) : zero_row_b;
+                unsigned valb = ia;
+                while (cnt > 0) {
+                    const int c64 = min(cnt, 64);
+                    const int steps = (c64 + 3) >> 2;          // wave-uniform
+                    if (steps > 12) {
+                        GNM_BLOCK16()                          // 16 ds_read_b128 in flight
+                    } else if (steps > 4) {
+                        GNM_BLOCK8(0)
+                        if (steps > 8) GNM_GROUP4(2)
+                    } else {
+                        GNM_GROUP4(0)
+                    }
+                    cnt -= 64;
+                    e0 += 64;
+                    if (cnt <= 0) break;
+                    if (e0 == beg + 64) {
+                        valb = ib;                             // second chunk was prefetched
+                    } else {                                   // degree > 128: fetch in place
+                        const unsigned rc = cl[e0 + jlane];
+                        valb = (jlane < cnt) ? rc * (FS * 4) : zero_row_b;
+                    }
+                }
+                racc[r] = acc;
+            }
+            // transposing combine: afterwards quarter q holds the full sum of row 4g + q
+            const float4 t02 = swap_add32(racc[0], racc[2]);   // lanes 0-31: row 0, lanes 32-63: row 2
+            const float4 t13 = swap_add32(racc[1], racc[3]);
+            float4 tot = swap_add16(t02, t13);
+
+            const int v = 4 * g + q;
+            if (v < n) {
+                const float4 self = tile[v * LPR + sub];
+                if (p.self_loop) acc4(tot, self);
+                if (!p.backward && p.average) {
+                    const float d = (float)(rp_s[v + 1] - rp_s[v] + p.self_loop);   // 0/0 -> NaN as in the reference
+                    tot.x /= d; tot.y /= d; tot.z /= d; tot.w /= d;
+                }
+                const int cc = col0 + 4 * sub;
+                if (!p.self_loop) {
+                    float4 sb = self;
+                    if (prescale) {
+                        const float* src = p.x + (size_t)(row0 + v) * p.ldx + cc;
+                        sb.x = (cc + 0 < p.F) ? src[0] : 0.f;
+                        sb.y = (cc + 1 < p.F) ? src[1] : 0.f;
+                        sb.z = (cc + 2 < p.F) ? src[2] : 0.f;
+                        sb.w = (cc + 3 < p.F) ? src[3] : 0.f;
+                    }
+                    tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
+                }
+                float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
+                if (vec_out && cc + 3 < p.F) {
+                    *reinterpret_cast<float4*>(dst) = tot;
+                } else {
+                    if (cc + 0 < p.F) dst[0] = tot.x;
+                    if (cc + 1 < p.F) dst[1] = tot.y;
+                    if (cc + 2 < p.F) dst[2] = tot.z;
+                    if (cc + 3 < p.F) dst[3] = tot.w;
+                }
+            }
+        }
+    }
+
+    if (p.deps_partial) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);
+        const double w = wave_sum_d(dot);
+        if (lane == 0) red[wave] = w;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int i = 0; i < nwaves; ++i) s += red[i];
+            p.deps_partial[blockIdx.x] = s;
+        }
+    }
+}
+
+static int launch_agg16(const AggArgs& a, int B, int n_max, hipStream_t stream) {
+    const size_t lds = (size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 16;
+    static bool configured = false;
+    if (!configured) {
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        configured = true;
+    }
+    int threads = 1024;
+    if (lds <= 20 * 1024) threads = 256;
+    else if (lds <= 48 * 1024) threads = 512;
+    if (const char* e = getenv("GNM_AGG16_THREADS")) {   // tuning knob for tools/bench_agg.py
+        const int t = atoi(e);
+        if (t >= 64 && t <= 1024 && (t & 63) == 0) threads = t;
+    }
+    hipLaunchKernelGGL(gnm_agg16_kernel, dim3(B * a.nslices), dim3(threads), lds, stream, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 template <int LPR>
 static int launch_agg(const AggArgs& a, int B, int n_max, hipStream_t stream) {
     const size_t lds = (size_t)(n_max + 1) * LPR * 16;
@@ -262,7 +586,7 @@ static int launch_agg(const AggArgs& a, int B, int n_max, hipStream_t stream) {
 extern "C" int gnm_agg_slice_width(int F, int n_max) {
     int fs = 8;
     while (fs < F && fs < 128) fs <<= 1;
-    while (fs >= 8 && (size_t)(n_max + 1) * fs * 4 > (size_t)kLdsBudget - 1024) fs >>= 1;
+    while (fs >= 8 && (size_t)(n_max + 1) * fs * 4 + (size_t)(n_max + 2) * 4 + 16 > (size_t)kLdsBudget - 1024) fs >>= 1;
     return fs >= 8 ? fs : 0;
 }
 
@@ -289,7 +613,7 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
         case 8: return launch_agg<2>(a, B, n_max, s);
         case 16: return launch_agg<4>(a, B, n_max, s);
         case 32: return launch_agg<8>(a, B, n_max, s);
-        case 64: return launch_agg<16>(a, B, n_max, s);
+        case 64: return launch_agg16(a, B, n_max, s);
         case 128: return launch_agg<32>(a, B, n_max, s);
     }
     return GNM_ERR_UNSUPPORTED;

@@ -19,8 +19,9 @@ from ._cabi import check, lib
 class _Growable:
     """1-D device buffer with amortised doubling growth."""
 
-    def __init__(self, dtype, device, width=None):
+    def __init__(self, dtype, device, width=None, slack=0):
         self.dtype, self.device, self.width = dtype, device, width
+        self.slack = slack            # elements kept allocated (and zeroed) past `size`
         self.size = 0
         shape = (0,) if width is None else (0, width)
         self.buf = torch.empty(shape, dtype=dtype, device=device)
@@ -28,10 +29,10 @@ class _Growable:
     def append(self, host_tensor):
         k = host_tensor.shape[0]
         need = self.size + k
-        if need > self.buf.shape[0]:
-            cap = max(need, 2 * self.buf.shape[0], 1024)
+        if need + self.slack > self.buf.shape[0]:
+            cap = max(need + self.slack, 2 * self.buf.shape[0], 1024)
             shape = (cap,) if self.width is None else (cap, self.width)
-            nb = torch.empty(shape, dtype=self.dtype, device=self.device)
+            nb = torch.zeros(shape, dtype=self.dtype, device=self.device)
             nb[: self.size].copy_(self.buf[: self.size])
             self.buf = nb
         self.buf[self.size:need].copy_(host_tensor, non_blocking=False)
@@ -55,7 +56,9 @@ class GraphArena:
     def __init__(self, device):
         self.device = torch.device(device)
         self.rowptr = _Growable(torch.int32, self.device)
-        self.col = _Growable(torch.int16, self.device)      # uint16 payload
+        # uint16 payload; the gather kernels fetch column ids 128 at a time without bounds
+        # branches, so 128 readable ids are kept past the last block (include/gnm_hip.h)
+        self.col = _Growable(torch.int16, self.device, slack=256)
         self.feat = None                                    # created on first add (needs F0)
         self.n, self.rp_off, self.col_off, self.t_rp_off, self.t_col_off, self.feat_off, self.nnz = [], [], [], [], [], [], []
         self.sym = []
