@@ -49,6 +49,7 @@ struct AggArgs {
     int F;                     // valid feature width
     int nslices;
     int average, self_loop, backward;
+    int debug;                 // tuning only (GNM_AGG16_DEBUG): 1 no id loads, 2 no epilogue/store, 4 no combine
 };
 
 template <int S>
@@ -446,6 +447,15 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         unsigned nra = cl[nbeg + jlane], nrb = cl[nbeg + 64 + jlane];
         for (int kk = 0; kk < ng; ++kk) {
             const int g = wave + (k0 + kk) * nwaves;
+            // this quarter's own row (for the self term): read it NOW, ahead of the gather, so it
+            // is not a dependent LDS round trip behind ~256 queued reads in the epilogue
+            const int v = 4 * g + q;
+            const float4 self = tile[min(v, n) * LPR + sub];
+            // degree of row v from the rowptr lane vector (no LDS): 5 readlanes + selects
+            const int b0 = __builtin_amdgcn_readlane(rpv, 8 * kk), b1 = __builtin_amdgcn_readlane(rpv, 8 * kk + 1),
+                      b2 = __builtin_amdgcn_readlane(rpv, 8 * kk + 2), b3 = __builtin_amdgcn_readlane(rpv, 8 * kk + 3),
+                      b4 = __builtin_amdgcn_readlane(rpv, 8 * kk + 4);
+            const int degv = (q == 0) ? b1 - b0 : (q == 1) ? b2 - b1 : (q == 2) ? b3 - b2 : b4 - b3;
             float4 racc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -459,8 +469,10 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 } else {
                     nend = nbeg;                               // nothing follows: an empty row at a valid address
                 }
-                nra = cl[nbeg + jlane];
-                nrb = cl[nbeg + 64 + jlane];
+                if (!(p.debug & 1)) {
+                    nra = cl[nbeg + jlane];
+                    nrb = cl[nbeg + 64 + jlane];
+                }
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 int cnt = end - beg;
                 int e0 = beg;
@@ -491,16 +503,21 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 racc[r] = acc;
             }
             // transposing combine: afterwards quarter q holds the full sum of row 4g + q
-            const float4 t02 = swap_add32(racc[0], racc[2]);   // lanes 0-31: row 0, lanes 32-63: row 2
-            const float4 t13 = swap_add32(racc[1], racc[3]);
-            float4 tot = swap_add16(t02, t13);
+            float4 tot;
+            if (p.debug & 4) {
+                tot = racc[0]; acc4(tot, racc[1]); acc4(tot, racc[2]); acc4(tot, racc[3]);
+            } else {
+                const float4 t02 = swap_add32(racc[0], racc[2]);   // lanes 0-31: row 0, lanes 32-63: row 2
+                const float4 t13 = swap_add32(racc[1], racc[3]);
+                tot = swap_add16(t02, t13);
+            }
 
-            const int v = 4 * g + q;
-            if (v < n) {
-                const float4 self = tile[v * LPR + sub];
+            if (p.debug & 2) {
+                if (tot.x == 12345.678f) p.y[0] = tot.y + tot.z + tot.w + self.x;   // keep values live
+            } else if (v < n) {
                 if (p.self_loop) acc4(tot, self);
                 if (!p.backward && p.average) {
-                    const float d = (float)(rp_s[v + 1] - rp_s[v] + p.self_loop);   // 0/0 -> NaN as in the reference
+                    const float d = (float)(degv + p.self_loop);   // 0/0 -> NaN as in the reference
                     tot.x /= d; tot.y /= d; tot.z /= d; tot.w /= d;
                 }
                 const int cc = col0 + 4 * sub;
@@ -607,6 +624,8 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
     a.ldx = ldx; a.ldy = ldy; a.ldh = ldh; a.F = F;
     a.nslices = (F + fs - 1) / fs;
     a.average = average; a.self_loop = self_loop; a.backward = backward;
+    a.debug = 0;
+    if (const char* e = getenv("GNM_AGG16_DEBUG")) a.debug = atoi(e);
     if (deps_partial && !hfwd) return GNM_ERR_BAD_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (fs) {

@@ -1,0 +1,351 @@
+"""Kernel-level GPU parity through the C-ABI (libgnm_hip.so), against the CPU oracle's op
+restatements (oracle/gin_oracle.py) evaluated in float64 on the same seeded inputs, plus
+size-independent properties at BASELINE.json's full sizes (n = 400, E = 47,600, B = 1024).
+
+Tolerance: 1e-5 relative (max-norm) for every fp32 kernel, written at each check."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-5
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class RG:
+    """random graph object with the S2VGraph fields the arena reads"""
+
+    def __init__(self, n, edge_mat, f0, rng):
+        self.g = range(n)
+        self.edge_mat = torch.from_numpy(np.ascontiguousarray(edge_mat.astype(np.int64)))
+        self.node_features = torch.from_numpy(rng.standard_normal((n, f0)).astype(np.float32))
+        self.label = 0
+
+
+def random_graphs(rng, sizes, density, symmetric=True, f0=3):
+    out = []
+    for n in sizes:
+        A = rng.random((n, n)) < density
+        np.fill_diagonal(A, False)
+        if symmetric:
+            A = np.triu(A, 1)
+            A = A | A.T
+        src, dst = np.nonzero(A)
+        out.append(RG(n, np.stack([src, dst]), f0, rng))
+    return out
+
+
+def dense_adj(batch_graphs):
+    """block-diagonal dense adjacency (float64), the oracle's coo_to_csr semantics"""
+    from oracle import gin_oracle as O
+    ob = [O.OGraph(len(g.g), g.edge_mat.numpy(), g.node_features.numpy()) for g in batch_graphs]
+    idx, val, shape = O.build_adj_block(ob, learn_eps=True)
+    return O.coo_to_csr(idx, val, shape, np.float64)
+
+
+AGG_CASES = [
+    # (sizes, density, F, symmetric)
+    ([40, 40, 40], 0.3, 64, True),        # headline shape class: LPR 16
+    ([37, 5, 64, 1, 23], 0.4, 64, True),  # ragged sizes incl. a single-node graph
+    ([50, 50], 0.0, 64, True),            # no edges at all
+    ([200, 200], 1.0, 64, True),          # complete graphs: degree 199 -> third id chunk fetched in place
+    ([30, 31], 0.3, 7, True),             # layer-0 width: LPR 2, scalar loads
+    ([30, 31], 0.3, 5, True),
+    ([64, 64], 0.2, 32, True),            # LPR 8
+    ([48, 48], 0.3, 16, True),            # LPR 4
+    ([300, 300], 0.05, 128, True),        # LPR 32
+    ([1000, 1000], 0.02, 128, True),      # config-4 class: tile does not fit -> 4 feature slices of 32
+    ([400, 400], 0.3, 400, True),         # one-hot width of the reference's default input: 7 slices of 64
+    ([45, 45, 45], 0.3, 64, False),       # asymmetric
+    ([45, 45, 45], 0.3, 20, False),       # asymmetric, partial slice, unaligned rows
+]
+
+
+@pytest.mark.parametrize("sizes,density,F,symmetric", AGG_CASES)
+@pytest.mark.parametrize("average,learn_eps", [(0, 1), (1, 1), (0, 0), (1, 0)])
+def test_agg_forward_backward(sizes, density, F, symmetric, average, learn_eps):
+    from gnm import core
+    from gnm.arena import GraphArena
+    rng = np.random.default_rng(hash((tuple(sizes), F)) % 2**31)
+    graphs = random_graphs(rng, sizes, density, symmetric)
+    ar = GraphArena(DEV)
+    batch = ar.batch(graphs)
+    assert batch.symmetric == (symmetric or density == 0.0)
+    A = dense_adj(graphs)
+    N = batch.N
+    deg = np.asarray(A.sum(1)).reshape(-1, 1)
+    x = rng.standard_normal((N, F))
+    eps = 0.37
+    spec = core.GinSpec(1, 1, bool(learn_eps), "sum", "average" if average else "sum")
+    xd = torch.from_numpy(x.astype(np.float32)).to(DEV)
+    yd = torch.full((N, F), float("nan"), device=DEV)
+    epsd = torch.tensor([eps], device=DEV)
+    core._agg(batch, xd, yd, F, epsd.data_ptr() if learn_eps else None, spec, backward=False)
+    x32 = xd.cpu().numpy().astype(np.float64)
+    # forward reference (graphcnn.py:154-161 / 178-182)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if learn_eps:
+            ref = A @ x32
+            if average:
+                ref = ref / deg
+            ref = ref + (1 + np.float32(eps).astype(np.float64)) * x32
+        else:
+            ref = A @ x32 + x32
+            if average:
+                ref = ref / (deg + 1)
+    assert_close(yd.cpu().numpy(), ref, rtol=TOL, what="agg forward")
+    # backward: dh = A^T (dp * pre) + self terms; deps = sum dp * h
+    dp = rng.standard_normal((N, F)).astype(np.float32)
+    dpd = torch.from_numpy(dp).to(DEV)
+    dhd = torch.full((N, F), float("nan"), device=DEV)
+    part = torch.empty(core.lib.gnm_agg_num_partials(F, batch.n_max, batch.B), dtype=torch.float64, device=DEV)
+    core._agg(batch, dpd, dhd, F, epsd.data_ptr() if learn_eps else None, spec, backward=True,
+              hfwd=xd if learn_eps else None, deps_partial=part if learn_eps else None)
+    dp64 = dp.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if learn_eps:
+            src = dp64 / deg if average else dp64
+            src = np.where(np.isfinite(src), src, 0.0)      # isolated rows are never gathered
+            refb = A.T @ src + (1 + np.float32(eps).astype(np.float64)) * dp64
+        else:
+            src = dp64 / (deg + 1) if average else dp64
+            refb = A.T @ src + src
+    assert_close(dhd.cpu().numpy(), refb, rtol=TOL, what="agg backward")
+    if learn_eps:
+        out = torch.empty(1, device=DEV)
+        core.check(core.lib.gnm_sum_partials(part.data_ptr(), part.numel(), out.data_ptr(), _stream()), "sum")
+        want = float((dp64 * x32).sum())
+        scale = float(np.abs(dp64 * x32).sum())
+        assert abs(out.item() - want) <= 1e-6 * scale        # fp64 accumulation: far below fp32 noise
+
+
+LIN_CASES = [(1000, 64, 64), (1000, 7, 64), (33, 64, 64), (1, 5, 32), (777, 128, 128), (500, 32, 32),
+             (640, 400, 64), (300, 64, 7), (300, 64, 128), (257, 16, 96), (4096, 64, 64)]
+
+
+@pytest.mark.parametrize("N,K,H", LIN_CASES)
+@pytest.mark.parametrize("pro", [False, True])
+def test_linear_forward_stats_and_grads(N, K, H, pro):
+    from gnm import core
+    from gnm._cabi import lib
+    rng = np.random.default_rng(N * 131 + K * 7 + H)
+    X = rng.standard_normal((N, K)).astype(np.float32)
+    W = (rng.standard_normal((H, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(H).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = rng.standard_normal(K).astype(np.float32)
+    Xd, Wd, bd = (torch.from_numpy(a).to(DEV) for a in (X, W, b))
+    scd, shd = torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV)
+    Z = torch.full((N, H), float("nan"), device=DEV)
+    grid = lib.gnm_linear_grid(N)
+    stats = torch.zeros((grid, 2, H), dtype=torch.float64, device=DEV)
+    core._linear(Xd, Wd, 0, bd, Z, N, K, H, (scd, shd) if pro else None, stats)
+    Xe = X.astype(np.float64)
+    if pro:
+        Xe = np.maximum(X * sc + sh, 0).astype(np.float64)  # fused BN-affine + ReLU prologue (mlp.py:48), fp32 like the kernel
+    ref = Xe @ W.astype(np.float64).T + b                    # nn.Linear (mlp.py:43,49)
+    assert_close(Z.cpu().numpy(), ref, rtol=TOL, what="linear fwd")
+    st = stats.sum(0).cpu().numpy()
+    z32 = Z.cpu().numpy().astype(np.float64)
+    assert_close(st[0], z32.sum(0), rtol=1e-6, what="column sums")
+    assert_close(st[1], (z32 ** 2).sum(0), rtol=1e-6, what="column sums of squares")
+    # dX = dZ W  (same kernel, k-major weight)
+    dZ = rng.standard_normal((N, H)).astype(np.float32)
+    dZd = torch.from_numpy(dZ).to(DEV)
+    dX = torch.full((N, K), float("nan"), device=DEV)
+    core._linear_wide(dZd, Wd, 1, None, dX, N, H, K, None, None)
+    assert_close(dX.cpu().numpy(), dZ.astype(np.float64) @ W.astype(np.float64), rtol=TOL, what="dgrad")
+    # dW = dZ^T f(X), db = sum dZ
+    dW = torch.full((H, K), float("nan"), device=DEV)
+    db = torch.full((H,), float("nan"), device=DEV)
+    ws = torch.empty(int(lib.gnm_wgrad_workspace_floats(N, H, K)), device=DEV)
+    core.check(lib.gnm_linear_wgrad(dZd.data_ptr(), H, Xd.data_ptr(), K, N, H, K, scd.data_ptr() if pro else None,
+                                    shd.data_ptr() if pro else None, 1 if pro else 0, dW.data_ptr(), K, db.data_ptr(),
+                                    ws.data_ptr(), _stream()), "wgrad")
+    assert_close(dW.cpu().numpy(), dZ.astype(np.float64).T @ Xe, rtol=TOL, what="wgrad")
+    assert_close(db.cpu().numpy(), dZ.astype(np.float64).sum(0), rtol=TOL, what="bias grad")
+
+
+@pytest.mark.parametrize("sizes,H", [([40, 40, 40], 64), ([13, 50, 7], 32), ([300, 300], 128), ([1], 64)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("average", [0, 1])
+def test_batchnorm_relu_readout_forward_backward(sizes, H, training, average):
+    """gnm_bn_finalize / gnm_bn_relu_readout / gnm_bn_relu_bwd_stats / _finalize / _apply vs
+    the oracle's bn_fwd / bn_bwd (torch.nn.BatchNorm1d semantics) and the readout spmm."""
+    from gnm._cabi import check, lib
+    from oracle import gin_oracle as O
+    rng = np.random.default_rng(sum(sizes) + H)
+    N, B = sum(sizes), len(sizes)
+    node_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    z = (rng.standard_normal((N, H)) * 2 + 3).astype(np.float32)
+    gamma = rng.uniform(0.5, 1.5, H).astype(np.float32)
+    beta = rng.standard_normal(H).astype(np.float32)
+    rm = rng.standard_normal(H).astype(np.float32)
+    rv = rng.uniform(0.5, 2, H).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    zd, gd, bd, rmd, rvd, nod = t(z), t(gamma), t(beta), t(rm.copy()), t(rv.copy()), t(node_off)
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    # statistics partials as the Linear epilogue would write them (2 blocks)
+    half = N // 2
+    parts = np.zeros((2, 2, H))
+    for i, sl in enumerate((slice(0, half), slice(half, N))):
+        parts[i, 0] = z[sl].astype(np.float64).sum(0)
+        parts[i, 1] = (z[sl].astype(np.float64) ** 2).sum(0)
+    pd = t(parts)
+    scale, shift, mean, rstd = (torch.empty(H, device=DEV) for _ in range(4))
+    check(lib.gnm_bn_finalize(pd.data_ptr(), 2, H, N, gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(),
+                              nbt.data_ptr(), 0.1, 1e-5, int(training), 1, scale.data_ptr(), shift.data_ptr(),
+                              mean.data_ptr(), rstd.data_ptr(), _stream()), "bn_finalize")
+    y, cache, (nrm, nrv) = O.bn_fwd(z.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64),
+                                    rm.astype(np.float64), rv.astype(np.float64), training)
+    if N > 1 or not training:
+        assert_close(rmd.cpu().numpy(), nrm, rtol=TOL, what="running_mean")
+        assert_close(rvd.cpu().numpy(), nrv, rtol=TOL, what="running_var")
+    assert int(nbt.item()) == (1 if training else 0)
+    hout = torch.full((N, H), float("nan"), device=DEV)
+    pooled = torch.full((B, 2 * H), float("nan"), device=DEV)      # strided destination (slice of g_f)
+    check(lib.gnm_bn_relu_readout(zd.data_ptr(), H, scale.data_ptr(), shift.data_ptr(), hout.data_ptr(), H,
+                                  nod.data_ptr(), B, H, 1, pooled[:, H:].data_ptr(), 2 * H, average, _stream()),
+          "bn_relu_readout")
+    href = np.maximum(y, 0)
+    if N > 1 or not training:
+        assert_close(hout.cpu().numpy(), href, rtol=TOL, what="relu(bn(z))")
+        pref = np.stack([href[node_off[b]:node_off[b + 1]].sum(0) * ((1.0 / sizes[b]) if average else 1.0)
+                         for b in range(B)])
+        assert_close(pooled[:, H:].cpu().numpy(), pref, rtol=TOL, what="readout")
+    if N == 1 and training:
+        return
+    # backward
+    dH = rng.standard_normal((N, H)).astype(np.float32)
+    dpool = rng.standard_normal((B, H)).astype(np.float32)
+    total = dH.astype(np.float64)
+    for b in range(B):
+        total[node_off[b]:node_off[b + 1]] += dpool[b] * ((1.0 / sizes[b]) if average else 1.0)
+    dy = total * (y > 0)
+    dx_ref, dg_ref, db_ref = O.bn_bwd(dy, cache)
+    G = torch.empty((N, H), device=DEV)
+    part = torch.empty((B, 2, H), dtype=torch.float64, device=DEV)
+    dHd, dpoold = t(dH), t(dpool)                     # keep the device copies alive across the launches
+    check(lib.gnm_bn_relu_bwd_stats(dHd.data_ptr(), H, dpoold.data_ptr(), H, average, None, None, 0, None, None,
+                                    zd.data_ptr(), H, scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                                    rstd.data_ptr(), 1, G.data_ptr(), H, nod.data_ptr(), B, H, part.data_ptr(),
+                                    _stream()), "bwd_stats")
+    dgam, dbet, cA, m1, m2 = (torch.empty(H, device=DEV) for _ in range(5))
+    check(lib.gnm_bn_bwd_finalize(part.data_ptr(), B, H, N, gd.data_ptr(), rstd.data_ptr(), int(training),
+                                  dgam.data_ptr(), dbet.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+                                  _stream()), "bwd_finalize")
+    check(lib.gnm_bn_bwd_apply(G.data_ptr(), H, zd.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), cA.data_ptr(),
+                               m1.data_ptr(), m2.data_ptr(), G.data_ptr(), H, N, H, _stream()), "bwd_apply")
+    floor = 1e-3 * float(np.abs(dy).max())
+    assert_close(G.cpu().numpy(), dx_ref, rtol=TOL, what="BN backward dx", floor=floor)
+    assert_close(dgam.cpu().numpy(), dg_ref, rtol=TOL, what="dgamma", floor=floor)
+    assert_close(dbet.cpu().numpy(), db_ref, rtol=TOL, what="dbeta", floor=floor)
+
+
+@pytest.mark.parametrize("B,n,L,H", [(3, 24, 5, 64), (4, 20, 3, 32), (2, 1, 2, 64), (5, 400, 5, 64)])
+def test_discriminator_scores_vs_literal_bilinear(B, n, L, H):
+    """gnm_disc_score_fwd/_bwd vs the literal nn.Bilinear formulation of discriminator.py:19-38
+    (oracle restatement), including the graph-index-as-row-index shuffle quirk."""
+    from gnm._cabi import check, lib
+    rng = np.random.default_rng(B * 100 + n)
+    N, LH = B * n, L * H
+    hs = [rng.standard_normal((N, H)).astype(np.float32) for _ in range(L)]
+    n_f = np.concatenate(hs, 1).astype(np.float64)
+    c = rng.uniform(0, 1, (B, LH)).astype(np.float32)
+    Wd = (rng.standard_normal((LH, LH)) / LH).astype(np.float32)
+    bias = np.float32(0.3)
+    perm = rng.permutation(B)
+    idx = np.repeat(perm, n)                                  # graphcnn.py:198-201
+    c_x = np.repeat(c.astype(np.float64), n, axis=0)
+    sc1 = ((n_f @ Wd.astype(np.float64)) * c_x).sum(1) + bias
+    sc2 = ((n_f[idx] @ Wd.astype(np.float64)) * c_x).sum(1) + bias
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    hd = [t(h) for h in hs]
+    U = t((c.astype(np.float64) @ Wd.astype(np.float64).T).astype(np.float32))
+    node_off = t(np.arange(B + 1, dtype=np.int32) * n)
+    perm_rows = t(perm.astype(np.int32))
+    d_logit = torch.empty(2 * N, device=DEV)
+    hp = (C.c_void_p * L)(*[h.data_ptr() for h in hd])
+    bd = t(np.array([bias]))
+    check(lib.gnm_disc_score_fwd(hp, H, L, H, U.data_ptr(), LH, perm_rows.data_ptr(), bd.data_ptr(),
+                                 node_off.data_ptr(), N, B, d_logit.data_ptr(), _stream()), "disc fwd")
+    assert_close(d_logit.cpu().numpy(), np.concatenate([sc1, sc2]), rtol=TOL, what="d_logit")
+    # backward wrt U and the negative-branch sums
+    dD = rng.standard_normal(2 * N).astype(np.float32)
+    dU = torch.empty((B, LH), device=DEV)
+    s2 = torch.empty(B, device=DEV)
+    dDd = t(dD)
+    check(lib.gnm_disc_score_bwd(hp, H, L, H, dDd.data_ptr(), perm_rows.data_ptr(), node_off.data_ptr(), N, B,
+                                 dU.data_ptr(), LH, s2.data_ptr(), _stream()), "disc bwd")
+    d1, d2 = dD[:N].astype(np.float64), dD[N:].astype(np.float64)
+    s2_ref = d2.reshape(B, n).sum(1)
+    dU_ref = np.stack([(d1[g * n:(g + 1) * n, None] * n_f[g * n:(g + 1) * n]).sum(0) + s2_ref[g] * n_f[perm[g]]
+                       for g in range(B)])
+    assert_close(s2.cpu().numpy(), s2_ref, rtol=TOL, what="s2sum", floor=1e-3 * np.abs(d2).max())
+    assert_close(dU.cpu().numpy(), dU_ref, rtol=TOL, what="dU", floor=1e-3 * np.abs(dU_ref).max())
+
+
+# ------------------------------------------------------------------ full-size properties
+@pytest.fixture(scope="module")
+def full_batch():
+    from gnm import synth
+    from gnm.arena import GraphArena
+    pool = synth.make_pool("dense_fc", 32)
+    ar = GraphArena(DEV)
+    gids = np.array([ar.add(g) for g in pool], dtype=np.int64)
+    rng = np.random.default_rng(0)
+    batch = ar.batch_from_gids(gids[rng.integers(0, 32, 1024)])
+    return pool, ar, batch
+
+
+def test_full_size_aggregation_properties(full_batch):
+    """B = 1024 x (n = 400, E = 47,600): exact edge count, linearity, the degree-weighted
+    column checksum sum_v (A x)_v = sum_u deg(u) x_u (symmetric graphs), and determinism."""
+    from gnm import core
+    pool, ar, batch = full_batch
+    assert all(int(g.edge_mat.shape[1]) == 47600 for g in pool)
+    N, F = batch.N, 64
+    assert N == 409600
+    spec = core.GinSpec(1, 1, True, "sum", "sum")
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(N, F, device=DEV, generator=g)
+    y = torch.randn(N, F, device=DEV, generator=g)
+    zero_eps = torch.tensor([-1.0], device=DEV)            # (1 + eps) = 0: pure neighbour sum
+    out = lambda v: (lambda o: (core._agg(batch, v, o, F, zero_eps.data_ptr(), spec, False), o)[1])(torch.empty_like(v))
+    ax, ay, axy = out(x), out(y), out(2.5 * x - 0.5 * y)
+    lin = 2.5 * ax - 0.5 * ay
+    assert (axy - lin).abs().max().item() <= 1e-5 * lin.abs().max().item()
+    assert torch.equal(out(x), ax)                        # fixed summation order: bitwise reproducible
+    # checksum of checksums in fp64 on the device
+    rp = ar.rowptr.buf[: ar.rowptr.size].to(torch.int64)
+    deg = torch.cat([(rp[o + 1:o + 401] - rp[o:o + 400]) for o in batch.rp_off.tolist()[:64]])   # first 64 graphs
+    lhs = ax[: 64 * 400].double().sum(0)
+    rhs = (deg.double()[:, None] * x[: 64 * 400].double()).sum(0)
+    assert (lhs - rhs).abs().max().item() <= 1e-6 * rhs.abs().max().item() + 1e-3
+
+
+def test_full_size_model_step_runs_and_is_deterministic(full_batch):
+    """One full training step at BASELINE configs[1] size; two runs agree bitwise."""
+    from models.graphcnn import GIN_InfoMaxReg
+    pool, ar, _ = full_batch
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        model = GIN_InfoMaxReg(5, 2, 7, 64, 2, 0.0, True, "sum", "sum", torch.device(DEV)).to(DEV).train()
+        arena = model.arena()
+        gids = np.array([arena.add(g) for g in pool], dtype=np.int64)
+        batch = arena.batch_from_gids(gids[np.random.default_rng(0).integers(0, 32, 1024)])
+        c, d = model.forward_batch(batch, perm=np.random.default_rng(1).permutation(1024))
+        assert c.shape == (1024, 2) and d.shape == (2 * 409600, 1)
+        (c.square().mean() + d.square().mean()).backward()
+        outs.append([c.detach().clone(), d.detach().clone()] + [p.grad.clone() for p in model.parameters()])
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
