@@ -18,6 +18,7 @@
 //     in the 32x32 C/D layout a lane owns one output COLUMN, so the statistics are
 //     register adds.
 #include "gnm_common.h"
+#include <stdlib.h>
 
 struct LinArgs {
     const float* X;
@@ -190,6 +191,203 @@ __global__ void __launch_bounds__(256) gnm_lin_kernel(const LinArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Pipelined variant for the common case: 16-B aligned rows, K a multiple of the chunk KC,
+// H == 32*HT.  No column guards; rows past N are clamped on load and masked in the
+// epilogue.  Differences from the generic kernel above:
+//   * the NEXT tile's global loads are issued right after this tile's A fragments are in
+//     registers, so they fly under the MFMAs (the generic kernel serialises load -> MFMA);
+//   * the output tile is transposed through the wave's staging image and stored as full
+//     16-B row-contiguous chunks (1 KiB per wave-instruction) instead of 4-B column pieces.
+// ---------------------------------------------------------------------------------
+template <int KC, int HT>
+__global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
+    constexpr int HP = HT * 32;
+    constexpr int XS = (KC > HP ? KC : HP) + 4;   // staging row stride: holds an input chunk or the output tile
+    constexpr int C4 = KC / 4;
+    constexpr int KH = KC / 2;
+    constexpr int NLD = (32 * C4) / 64;           // float4 loads per lane per chunk (KC >= 8)
+    constexpr int O4 = HP / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nchunks = p.K / KC;
+    float* Wt = reinterpret_cast<float*>(smem);                   // [K][HP]
+    float* Xs_all = Wt + (size_t)p.K * HP;                        // [4][32][XS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    float* Xs = Xs_all + wave * 32 * XS;
+
+    if (p.w_kmajor) {
+        for (int idx = tid; idx < p.K * HP; idx += 256) {
+            const int k = idx / HP, hh = idx - k * HP;
+            Wt[idx] = p.W[(size_t)k * p.ldw + hh];
+        }
+    } else {
+        for (int idx = tid; idx < p.K * HP; idx += 256) {
+            const int hh = idx / p.K, k = idx - hh * p.K;
+            Wt[k * HP + hh] = p.W[(size_t)hh * p.ldw + k];
+        }
+    }
+    __syncthreads();
+
+    const int ntiles = (p.N + 31) / 32;
+    double st1[HT], st2[HT];
+    float bias_r[HT];
+#pragma unroll
+    for (int c = 0; c < HT; ++c) {
+        st1[c] = 0.0; st2[c] = 0.0;
+        bias_r[c] = p.bias ? p.bias[32 * c + i] : 0.f;
+    }
+    const int c4 = lane % C4;
+    const int lrow0 = lane / C4;                  // row of this lane's first float4; later ones are +64/C4 rows
+    constexpr int RSTEP = 64 / C4;
+    const int tstride = gridDim.x * 4;
+    const int nlast = p.N - 1;
+
+    float4 raw[NLD];
+    int t = blockIdx.x * 4 + wave;
+    if (t < ntiles) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int grow = min(t * 32 + lrow0 + j * RSTEP, nlast);
+            raw[j] = *reinterpret_cast<const float4*>(p.X + (size_t)grow * p.ldx + 4 * c4);
+        }
+    }
+    for (; t < ntiles; t += tstride) {
+        const int r0 = t * 32;
+        f32x16 acc[HT];
+#pragma unroll
+        for (int c = 0; c < HT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const int kb = kc * KC;
+            if (p.pro_scale) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.pro_scale + kb + 4 * c4);
+                const float4 sh = *reinterpret_cast<const float4*>(p.pro_shift + kb + 4 * c4);
+#pragma unroll
+                for (int j = 0; j < NLD; ++j) {
+                    float4 v = raw[j];
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                    if (p.pro_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    raw[j] = v;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NLD; ++j)
+                *reinterpret_cast<float4*>(Xs + (lrow0 + j * RSTEP) * XS + 4 * c4) = raw[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float a[KH];
+#pragma unroll
+            for (int j = 0; j < KH / 4; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 4 * j);
+                a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+            }
+            // next chunk (of this tile, or chunk 0 of this wave's next tile): loads fly under the MFMAs
+            {
+                const bool more_k = kc + 1 < nchunks;
+                const int tn = more_k ? t : t + tstride;
+                const int kn = more_k ? kb + KC : 0;
+                if (tn < ntiles) {
+#pragma unroll
+                    for (int j = 0; j < NLD; ++j) {
+                        const int grow = min(tn * 32 + lrow0 + j * RSTEP, nlast);
+                        raw[j] = *reinterpret_cast<const float4*>(p.X + (size_t)grow * p.ldx + kn + 4 * c4);
+                    }
+                }
+            }
+            const float* wrow = Wt + (size_t)(kb + KH * h) * HP + i;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) {
+#pragma unroll
+                for (int c = 0; c < HT; ++c) {
+                    const float bv = wrow[s * HP + 32 * c];
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv, acc[c], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // epilogue: bias, statistics (valid rows only), transpose through LDS, 16-B stores
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float z = acc[c][r] + bias_r[c];
+                Xs[lrow * XS + 32 * c + i] = z;
+                if (r0 + lrow < p.N) {
+                    s1 += z;
+                    s2 += z * z;
+                }
+            }
+            st1[c] += (double)s1;
+            st2[c] += (double)s2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int idx = lane; idx < 32 * O4; idx += 64) {
+            const int row = idx / O4, oc = idx - row * O4;
+            if (r0 + row < p.N)
+                *reinterpret_cast<float4*>(p.Z + (size_t)(r0 + row) * p.ldz + 4 * oc) =
+                    *reinterpret_cast<const float4*>(Xs + row * XS + 4 * oc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    if (p.stats_partial) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);   // [4 waves][2][HP]
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            const double a1 = st1[c] + __shfl_xor(st1[c], 32, 64);
+            const double a2 = st2[c] + __shfl_xor(st2[c], 32, 64);
+            if (h == 0) {
+                red[(wave * 2 + 0) * HP + 32 * c + i] = a1;
+                red[(wave * 2 + 1) * HP + 32 * c + i] = a2;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * HP; idx += 256) {
+            const int which = idx / HP, col = idx - which * HP;
+            double s = 0.0;
+            for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * HP + col];
+            p.stats_partial[((size_t)blockIdx.x * 2 + which) * p.H + col] = s;
+        }
+    }
+}
+
+template <int KC, int HT>
+static int launch_lin_fast(const LinArgs& a, int grid, hipStream_t s) {
+    constexpr int HP = HT * 32;
+    constexpr int XS = (KC > HP ? KC : HP) + 4;
+    size_t lds = (size_t)a.K * HP * 4 + (size_t)4 * 32 * XS * 4;
+    const size_t red = (size_t)4 * 2 * HP * 8;
+    if (red > lds) lds = red;
+    if (lds > (size_t)kLdsBudget) return GNM_ERR_UNSUPPORTED;
+    static bool configured = false;
+    if (!configured) {
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_lin_fast_kernel<KC, HT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gnm_lin_fast_kernel<KC, HT>), dim3(grid), dim3(256), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 static size_t lin_lds_bytes(int K, int KC, int HT) {
     const int KP = ((K + KC - 1) / KC) * KC;
     size_t b = (size_t)KP * HT * 32 * 4 + (size_t)4 * 32 * (KC + 4) * 4;
@@ -235,6 +433,19 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
     const int grid = gnm_linear_grid(N);
     const int HT = (H + 31) / 32;
     const int kc = K <= 8 ? 8 : (K <= 16 ? 16 : (K <= 32 ? 32 : 64));
+    // pipelined variant: aligned rows in and out, no partial chunks or partial output tiles
+    const bool aligned = ((ldx & 3) == 0) && ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(Z) & 15) == 0) &&
+                         (!pro_scale || (((reinterpret_cast<uintptr_t>(pro_scale) | reinterpret_cast<uintptr_t>(pro_shift)) & 15) == 0));
+    if (aligned && (H % 32) == 0 && (K % 32) == 0 && !getenv("GNM_LIN_GENERIC")) {
+        const int kcf = (K % 64) == 0 ? 64 : 32;
+        int rc = GNM_ERR_UNSUPPORTED;
+#define GNM_LINF_CASE(KC_, HT_) if (kcf == KC_ && HT == HT_) rc = launch_lin_fast<KC_, HT_>(a, grid, s);
+        GNM_LINF_CASE(32, 1) GNM_LINF_CASE(32, 2) GNM_LINF_CASE(32, 3) GNM_LINF_CASE(32, 4)
+        GNM_LINF_CASE(64, 1) GNM_LINF_CASE(64, 2) GNM_LINF_CASE(64, 3) GNM_LINF_CASE(64, 4)
+#undef GNM_LINF_CASE
+        if (rc != GNM_ERR_UNSUPPORTED) return rc;      // too large for LDS: fall through to the generic kernel
+    }
 #define GNM_LIN_CASE(KC_, HT_) if (kc == KC_ && HT == HT_) return launch_lin<KC_, HT_>(a, grid, s);
     GNM_LIN_CASE(8, 1) GNM_LIN_CASE(8, 2) GNM_LIN_CASE(8, 3) GNM_LIN_CASE(8, 4)
     GNM_LIN_CASE(16, 1) GNM_LIN_CASE(16, 2) GNM_LIN_CASE(16, 3) GNM_LIN_CASE(16, 4)
@@ -382,6 +593,141 @@ __global__ void __launch_bounds__(256) gnm_wgrad_kernel(const WgArgs p) {
     }
 }
 
+// Pipelined wgrad for H % 32 == 0 and K-window % 32 == 0: no column guards, rows clamped on
+// load and zeroed by select, and U row-pairs (U*(WI+WJ) loads) in flight before their MFMAs.
+// The generic kernel above waits for every pair's 4 loads before its 4 MFMAs.
+template <int WI, int WJ, int QI, int QJ>
+__global__ void __launch_bounds__(256) gnm_wgrad_fast_kernel(const WgArgs p) {
+    constexpr int NQ = QI * QJ;
+    constexpr int RSPLIT = 4 / NQ;
+    constexpr int U = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dump = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int q = wave % NQ, rs = wave / NQ;
+    const int qi = q / QJ, qj = q % QJ;
+
+    f32x16 acc[WI][WJ];
+#pragma unroll
+    for (int a = 0; a < WI; ++a)
+#pragma unroll
+        for (int b = 0; b < WJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float dbacc[WI];
+    int hcol[WI], kcol[WJ];
+    float sc[WJ], sh[WJ];
+#pragma unroll
+    for (int a = 0; a < WI; ++a) { dbacc[a] = 0.f; hcol[a] = 32 * (qi * WI + a) + i; }
+#pragma unroll
+    for (int b = 0; b < WJ; ++b) {
+        kcol[b] = p.k0 + 32 * (qj * WJ + b) + i;
+        sc[b] = p.pro_scale ? p.pro_scale[kcol[b]] : 1.f;
+        sh[b] = p.pro_scale ? p.pro_shift[kcol[b]] : 0.f;
+    }
+    const int rb = blockIdx.x * p.rows_per_block;
+    const int re = min(p.N, rb + p.rows_per_block);
+    const int nlast = p.N - 1;
+    for (int n0 = rb + 2 * rs; n0 < re; n0 += 2 * RSPLIT * U) {
+        float av[U][WI], bv[U][WJ];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int n = n0 + u * 2 * RSPLIT + h;
+            const int nc = min(n, nlast);
+#pragma unroll
+            for (int a = 0; a < WI; ++a) av[u][a] = p.dZ[(size_t)nc * p.ldd + hcol[a]];
+#pragma unroll
+            for (int b = 0; b < WJ; ++b) bv[u][b] = p.X[(size_t)nc * p.ldx + kcol[b]];
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep all U*(WI+WJ) loads ahead of the MFMAs
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool rok = (n0 + u * 2 * RSPLIT + h) < re;
+#pragma unroll
+            for (int b = 0; b < WJ; ++b) {
+                float x = bv[u][b];
+                if (p.pro_scale) {
+                    x = x * sc[b] + sh[b];
+                    if (p.pro_relu) x = fmaxf(x, 0.f);
+                }
+                bv[u][b] = rok ? x : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < WI; ++a) {
+                const float d = rok ? av[u][a] : 0.f;
+                dbacc[a] += d;
+#pragma unroll
+                for (int b = 0; b < WJ; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(d, bv[u][b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    constexpr int TILE = 16 * 64;
+    float* mine = dump + (size_t)wave * WI * WJ * TILE;
+#pragma unroll
+    for (int a = 0; a < WI; ++a)
+#pragma unroll
+        for (int b = 0; b < WJ; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(a * WJ + b) * TILE + r * 64 + lane] = acc[a][b][r];
+    float* dbdump = dump + (size_t)4 * WI * WJ * TILE;
+#pragma unroll
+    for (int a = 0; a < WI; ++a) dbdump[(wave * WI + a) * 64 + lane] = dbacc[a];
+    __syncthreads();
+
+    float* out = p.partial + (size_t)blockIdx.x * ((size_t)p.H * p.kw + p.H);
+    for (int idx = tid; idx < NQ * WI * WJ * TILE; idx += 256) {
+        const int qq = idx / (WI * WJ * TILE);
+        const int rem = idx - qq * (WI * WJ * TILE);
+        const int ab = rem / TILE;
+        const int rl = rem - ab * TILE;
+        const int r = rl >> 6, ln = rl & 63;
+        const int a = ab / WJ, b = ab - a * WJ;
+        const int row = 32 * ((qq / QJ) * WI + a) + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int colw = 32 * ((qq % QJ) * WJ + b) + (ln & 31);
+        if (row < p.H && colw < p.kw) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < RSPLIT; ++w) s += dump[(size_t)(w * NQ + qq) * WI * WJ * TILE + rem];
+            out[(size_t)row * p.kw + colw] = s;
+        }
+    }
+    for (int idx = tid; idx < QI * WI * 32; idx += 256) {
+        const int qqi = idx / (WI * 32);
+        const int rem = idx - qqi * (WI * 32);
+        const int a = rem >> 5, ii = rem & 31;
+        const int hh = 32 * (qqi * WI + a) + ii;
+        if (hh < p.H) {
+            float s = 0.f;
+            const int qq = qqi * QJ;
+#pragma unroll
+            for (int w = 0; w < RSPLIT; ++w) {
+                const int wv = w * NQ + qq;
+                s += dbdump[(wv * WI + a) * 64 + ii] + dbdump[(wv * WI + a) * 64 + 32 + ii];
+            }
+            out[(size_t)p.H * p.kw + hh] = s;
+        }
+    }
+}
+
+template <int WI, int WJ, int QI, int QJ>
+static int launch_wgrad_fast(const WgArgs& a, int grid, hipStream_t s) {
+    const size_t lds = ((size_t)4 * WI * WJ * 1024 + (size_t)4 * WI * 64) * 4;
+    static bool configured = false;
+    if (!configured) {
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_wgrad_fast_kernel<WI, WJ, QI, QJ>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gnm_wgrad_fast_kernel<WI, WJ, QI, QJ>), dim3(grid), dim3(256), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 template <int WI, int WJ, int QI, int QJ>
 static int launch_wgrad(const WgArgs& a, int grid, hipStream_t s) {
     const size_t lds = ((size_t)4 * WI * WJ * 1024 + (size_t)4 * WI * 64) * 4;
@@ -398,7 +744,7 @@ static int launch_wgrad(const WgArgs& a, int grid, hipStream_t s) {
 
 extern "C" int gnm_wgrad_grid(int N) {
     int g = (N + 511) / 512;            // >= 512 rows per block
-    if (g > 512) g = 512;
+    if (g > 256) g = 256;               // one block per CU: fewer partials to reduce
     return g < 1 ? 1 : g;
 }
 
@@ -416,16 +762,17 @@ __global__ void gnm_reduce_partials_kernel(const float* __restrict__ partial, in
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     const int count = H * kw + H;
     if (e >= count) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
     int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += partial[(size_t)(b + 0) * stride + e];
-        s1 += partial[(size_t)(b + 1) * stride + e];
-        s2 += partial[(size_t)(b + 2) * stride + e];
-        s3 += partial[(size_t)(b + 3) * stride + e];
+    for (; b + 7 < nblk; b += 8) {          // 8 independent loads in flight, fixed summation order
+        const float v0 = partial[(size_t)(b + 0) * stride + e], v1 = partial[(size_t)(b + 1) * stride + e];
+        const float v2 = partial[(size_t)(b + 2) * stride + e], v3 = partial[(size_t)(b + 3) * stride + e];
+        const float v4 = partial[(size_t)(b + 4) * stride + e], v5 = partial[(size_t)(b + 5) * stride + e];
+        const float v6 = partial[(size_t)(b + 6) * stride + e], v7 = partial[(size_t)(b + 7) * stride + e];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
     }
     for (; b < nblk; ++b) s0 += partial[(size_t)b * stride + e];
-    const float s = (s0 + s1) + (s2 + s3);
+    const float s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
     if (e < H * kw) {
         const int row = e / kw, col = e - row * kw;
         dW[(size_t)row * ldw + k0 + col] = s;
@@ -455,8 +802,10 @@ extern "C" int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ld
         const int WI = HT < 2 ? HT : 2, WJ = KT < 2 ? KT : 2;
         const int QI = (HT + WI - 1) / WI, QJ = (KT + WJ - 1) / WJ;
         int rc = GNM_ERR_UNSUPPORTED;
-#define GNM_WG_CASE(WI_, WJ_, QI_, QJ_) \
-    if (WI == WI_ && WJ == WJ_ && QI == QI_ && QJ == QJ_) rc = launch_wgrad<WI_, WJ_, QI_, QJ_>(a, grid, s);
+        const bool fast = (H % 32) == 0 && (kw % 32) == 0 && N > 0 && !getenv("GNM_LIN_GENERIC");
+#define GNM_WG_CASE(WI_, WJ_, QI_, QJ_)                                                       \
+    if (WI == WI_ && WJ == WJ_ && QI == QI_ && QJ == QJ_)                                     \
+        rc = fast ? launch_wgrad_fast<WI_, WJ_, QI_, QJ_>(a, grid, s) : launch_wgrad<WI_, WJ_, QI_, QJ_>(a, grid, s);
         GNM_WG_CASE(1, 1, 1, 1) GNM_WG_CASE(1, 2, 1, 1) GNM_WG_CASE(1, 2, 1, 2)
         GNM_WG_CASE(2, 1, 1, 1) GNM_WG_CASE(2, 2, 1, 1) GNM_WG_CASE(2, 2, 1, 2)
         GNM_WG_CASE(2, 1, 2, 1) GNM_WG_CASE(2, 2, 2, 1) GNM_WG_CASE(2, 2, 2, 2)

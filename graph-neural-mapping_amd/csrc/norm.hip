@@ -22,9 +22,25 @@ __device__ __forceinline__ void reduce_partials_1024(const double* partial, int 
     const int groups = 1024 / ncols;
     const int g = tid / ncols, c = tid - g * ncols;
     double s = 0.0;
-    if (g < groups)
-        for (int b = g; b < nblk; b += groups) s += partial[(size_t)b * ncols + c];
-    if (g < groups) lds[g * ncols + c] = s;
+    if (g < groups) {
+        // 8 independent loads in flight per thread (the chain of adds is short; the loads are not)
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+        int b = g;
+        for (; b + 7 * groups < nblk; b += 8 * groups) {
+            const double v0 = partial[(size_t)(b + 0 * groups) * ncols + c];
+            const double v1 = partial[(size_t)(b + 1 * groups) * ncols + c];
+            const double v2 = partial[(size_t)(b + 2 * groups) * ncols + c];
+            const double v3 = partial[(size_t)(b + 3 * groups) * ncols + c];
+            const double v4 = partial[(size_t)(b + 4 * groups) * ncols + c];
+            const double v5 = partial[(size_t)(b + 5 * groups) * ncols + c];
+            const double v6 = partial[(size_t)(b + 6 * groups) * ncols + c];
+            const double v7 = partial[(size_t)(b + 7 * groups) * ncols + c];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+        }
+        for (; b < nblk; b += groups) s0 += partial[(size_t)b * ncols + c];
+        s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        lds[g * ncols + c] = s;
+    }
     __syncthreads();
     if (tid < ncols) {
         double t = 0.0;
