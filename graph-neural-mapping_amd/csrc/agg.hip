@@ -430,6 +430,17 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     // cycles deep, so row bounds come from a lane vector loaded once per 8 groups
     // (v_readlane), column ids are fetched one row ahead, and the 4-row combine below is
     // pure VALU (v_permlane32_swap / v_permlane16_swap).
+    if (p.debug & 8) {   // tuning: the micro-benchmark's steady-state loop, same step count (2 x 16 per row)
+        unsigned valb = (unsigned)((lane * 37 + 11) % max(n, 1)) * (FS * 4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int g = wave; g < ngroups; g += nwaves)
+            for (int r = 0; r < 8; ++r) {
+                GNM_BLOCK16()
+                valb ^= 256;
+            }
+        if (acc.x == 12345.678f) p.y[0] = acc.y + acc.z + acc.w;
+        return;
+    }
     for (int k0 = 0; wave + k0 * nwaves < ngroups; k0 += 8) {
         int rpv = 0;
         {

@@ -16,7 +16,11 @@ struct HPtrs {
     const float* p[GNM_MAX_LAYERS];
 };
 
-// d_logit[v] = sc_1[v], d_logit[N + v] = sc_2[g(v)]; one workgroup per graph, one wave per row.
+// d_logit[v] = sc_1[v], d_logit[N + v] = sc_2[g(v)]; one workgroup per graph.
+// A row of layer l is covered by H/4 lanes with 16-B loads (G = 64/(H/4) rows per
+// wave-instruction when H/4 divides 64, e.g. 4 rows at H = 64); the lane group reduces its
+// dot product with DPP/shuffle steps inside the group.  Generic widths use one wave per row.
+template <int LPR4>   // lanes per row (H/4), a power of two <= 64; 0 = generic
 __global__ void __launch_bounds__(256) gnm_disc_score_kernel(const HPtrs hp, int ldh, int L, int H,
                                                              const float* __restrict__ U, int ldu,
                                                              const int32_t* __restrict__ perm_rows,
@@ -44,15 +48,37 @@ __global__ void __launch_bounds__(256) gnm_disc_score_kernel(const HPtrs hp, int
     }
     __syncthreads();
     const float sc2 = sc2s[0];
-    for (int r = wave; r < n; r += 4) {
-        const int v = row0 + r;
-        float a = 0.f;
-        for (int l = 0; l < L; ++l)
-            for (int c = lane; c < H; c += 64) a += hp.p[l][(size_t)v * ldh + c] * Us[l * H + c];
-        a = wave_sum(a);
-        if (lane == 0) {
-            d_logit[v] = a + bv;
-            d_logit[(size_t)N + v] = sc2;
+    if (n <= 0) return;
+    if constexpr (LPR4 > 0) {
+        constexpr int G = 64 / LPR4;                   // rows per wave-instruction
+        const int sub = lane & (LPR4 - 1), slot = lane / LPR4;
+        for (int r = wave * G + slot; r < n + G - 1; r += 4 * G) {   // uniform trip count per wave
+            const int rr = min(r, n - 1);
+            const int v = row0 + rr;
+            float a = 0.f;
+            for (int l = 0; l < L; ++l) {
+                const float4 x = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);
+                const float4 u = *reinterpret_cast<const float4*>(Us + l * H + 4 * sub);
+                a += x.x * u.x + x.y * u.y + x.z * u.z + x.w * u.w;
+            }
+#pragma unroll
+            for (int off = LPR4 >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+            if (sub == 0 && r < n) {
+                d_logit[v] = a + bv;
+                d_logit[(size_t)N + v] = sc2;
+            }
+        }
+    } else {
+        for (int r = wave; r < n; r += 4) {
+            const int v = row0 + r;
+            float a = 0.f;
+            for (int l = 0; l < L; ++l)
+                for (int c = lane; c < H; c += 64) a += hp.p[l][(size_t)v * ldh + c] * Us[l * H + c];
+            a = wave_sum(a);
+            if (lane == 0) {
+                d_logit[v] = a + bv;
+                d_logit[(size_t)N + v] = sc2;
+            }
         }
     }
 }
@@ -64,9 +90,18 @@ extern "C" int gnm_disc_score_fwd(const float* const* hptrs, int ldh, int L, int
     if (L <= 0 || L > GNM_MAX_LAYERS || H <= 0) return GNM_ERR_BAD_ARG;
     HPtrs hp;
     for (int l = 0; l < GNM_MAX_LAYERS; ++l) hp.p[l] = l < L ? hptrs[l] : nullptr;
-    hipLaunchKernelGGL(gnm_disc_score_kernel, dim3(B), dim3(256), (size_t)(L * H + 4) * 4,
-                       reinterpret_cast<hipStream_t>(stream), hp, ldh, L, H, U, ldu, perm_rows, bias, node_off, N,
-                       d_logit);
+    const size_t lds = (size_t)(L * H + 4) * 4;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool vec = ((ldh & 3) == 0) && ((H & 3) == 0);
+    const int lpr4 = vec ? H / 4 : 0;
+#define GNM_DISC_CASE(V) \
+    hipLaunchKernelGGL(gnm_disc_score_kernel<V>, dim3(B), dim3(256), lds, st, hp, ldh, L, H, U, ldu, perm_rows, bias, \
+                       node_off, N, d_logit)
+    if (lpr4 == 8) GNM_DISC_CASE(8);
+    else if (lpr4 == 16) GNM_DISC_CASE(16);
+    else if (lpr4 == 32) GNM_DISC_CASE(32);
+    else GNM_DISC_CASE(0);
+#undef GNM_DISC_CASE
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
