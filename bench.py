@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--pool", type=int, default=None, help="distinct graphs resident per GPU (default = batch)")
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--layers", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+                    help="c2: 400-node dense-FC graphs, hidden 64 (headline); c4: 1000-node kNN k=20, hidden 128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
@@ -108,12 +110,16 @@ def main():
     from gnm.parallel import DataParallelGIN, seed_rank_rng
     from models.graphcnn import GIN_InfoMaxReg
 
-    B = args.batch or (1024 if world == 1 else 512)
-    pool_n = args.pool or B
-    n, f0, H, L, C = 400, 7, args.hidden, args.layers, 2
+    sparse = args.config == "c4"
+    B = args.batch or ((1024 if world == 1 else 512) if not sparse else 256)
+    pool_n = args.pool or (B if not sparse else 64)
+    n, f0, H, L, C = (1000 if sparse else 400), 7, (128 if sparse else args.hidden), args.layers, 2
 
     t_gen = time.perf_counter()
-    pool = synth.make_pool("dense_fc", pool_n, first=rank * pool_n, n=n, f0=f0)
+    if sparse:
+        pool = synth.make_pool("knn", pool_n, first=rank * pool_n, n=n, f0=f0)
+    else:
+        pool = synth.make_pool("dense_fc", pool_n, first=rank * pool_n, n=n, f0=f0)
     torch.manual_seed(0)
     model = GIN_InfoMaxReg(L, 2, f0, H, C, 0.5, True, "sum", "sum", dev).to(dev)
     state_cpu = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
@@ -156,6 +162,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, nsteps):
         loss = step(i)
+    t_enqueued = time.perf_counter() - t0        # host time to enqueue all steps (no sync inside)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -173,18 +180,21 @@ def main():
     if rank == 0:
         total_graphs = B * world * args.steps
         out = {
-            "metric": "graphs/sec fwd+bwd, 400-node dense FC graphs, hidden_dim 64, 5 layers",
+            "metric": "graphs/sec fwd+bwd, 400-node dense FC graphs, hidden_dim 64, 5 layers" if not sparse else
+                      "graphs/sec fwd+bwd, 1000-node kNN(k=20) graphs, hidden_dim 128, 5 layers (BASELINE configs[3])",
             "value": total_graphs / elapsed, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[%d]: %d x %d dense-FC 400-node graphs/step (47,600 directed edges each), "
+            "config": {"workload": "configs[%d]: %d x %d %s graphs/step (%d directed edges each), "
                                    "F0=7, hidden %d, %d GIN layers, 2-layer MLP, sum/sum, learn_eps, "
                                    "full forward (classifier + Infomax discriminator) + CE+0.05*BCE + backward%s"
-                                   % (1 if world == 1 else 2, world, B, H, L,
+                                   % (3 if sparse else (1 if world == 1 else 2), world, B,
+                                      "1000-node kNN(k=20)" if sparse else "dense-FC 400-node", E, H, L,
                                       ", flat-gradient RCCL all-reduce" if world > 1 else ""),
                        "graphs_per_gpu": B, "global_batch": B * world, "nodes_per_graph": n, "edges_per_graph": E,
                        "pool_graphs_per_gpu": pool_n, "parallelism": "dp%d" % world},
             "final_loss": loss_val, "setup_seconds": round(t_gen, 1),
+            "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
         }
         roof, roof_mlp = None, None
         if timer is not None:
@@ -195,9 +205,15 @@ def main():
                 c, ms, meta = summ[key]
                 bytes_launch = AGG_BYTES_PER_GRAPH_LAYER(n, E, H) * meta["B"]
                 ach = bytes_launch / (ms * 1e-3) / 1e9
-                roof = {"bound": "hbm", "kernel": "gnm_agg_kernel<16> (forward, F=%d)" % H, "achieved": ach,
+                traffic, traffic_src = None, None
+                tp = os.path.join(ROOT, "profiles", "agg16_traffic.json")
+                if os.path.exists(tp) and meta["B"] == 1024 and H == 64:
+                    tj = json.load(open(tp))      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_agg.sh)
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], tj["source"]
+                roof = {"bound": "hbm", "kernel": "gnm_agg16_kernel (forward, F=%d)" % H, "achieved": ach,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "frac_of_measured_copy_peak": ach / HBM_MEASURED_GBS, "traffic": None,
+                        "frac_of_measured_copy_peak": ach / HBM_MEASURED_GBS, "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": bytes_launch, "mean_launch_ms": ms, "launches_timed": c,
                         "graph_layers_per_s": meta["B"] / (ms * 1e-3)}
             key = "lin_fwd_K%d_H%d" % (H, H)
@@ -211,7 +227,7 @@ def main():
                             "hbm_GBs": (meta["N"] * H * 4 * 2) / (ms * 1e-3) / 1e9}
         out["roofline"] = roof
         out["roofline_mlp"] = roof_mlp
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not sparse:
             out["cpu_baseline"] = cpu_baseline(pool[:32], state_cpu)
         else:
             out["cpu_baseline"] = None

@@ -13,39 +13,38 @@
 #include "gnm_common.h"
 
 // ---------------------------------------------------------------------------------
-// column-partial reduction shared by the two finalize kernels
-// partial: [nblk][ncols] doubles -> red[c] for c < ncols (ncols <= 256), fixed order
+// column-partial reduction shared by the two finalize kernels.
+// partial: [nblk][2][H] doubles.  A workgroup owns a slice of CW = 16 columns (both the
+// "sum" and the "second sum" halves), so the grid is H/16 workgroups and each streams only
+// its 2*16 columns of every partial row: one workgroup reading all ~0.8 MB of partials is
+// limited to a single CU's bandwidth (~16 us), H/16 of them are not.  Fixed summation order.
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ void reduce_partials_1024(const double* partial, int nblk, int ncols, double* lds,
-                                                      double* result) {
-    const int tid = threadIdx.x;
-    const int groups = 1024 / ncols;
-    const int g = tid / ncols, c = tid - g * ncols;
-    double s = 0.0;
-    if (g < groups) {
-        // 8 independent loads in flight per thread (the chain of adds is short; the loads are not)
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0, s7 = 0.0;
+static constexpr int kFinCols = 16;
+
+__device__ __forceinline__ void reduce_partials_slice(const double* partial, int nblk, int H, int c0, double* lds,
+                                                      double* tot /*[2*kFinCols]*/) {
+    constexpr int NC = 2 * kFinCols;              // columns handled here: 16 of each half
+    const int tid = threadIdx.x;                  // 1024 threads = 32 row groups x 32 columns
+    const int g = tid / NC, cc = tid - g * NC;
+    const int which = cc / kFinCols, c = c0 + (cc - which * kFinCols);
+    constexpr int groups = 1024 / NC;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < H) {
+        const double* base = partial + (size_t)which * H + c;
         int b = g;
-        for (; b + 7 * groups < nblk; b += 8 * groups) {
-            const double v0 = partial[(size_t)(b + 0 * groups) * ncols + c];
-            const double v1 = partial[(size_t)(b + 1 * groups) * ncols + c];
-            const double v2 = partial[(size_t)(b + 2 * groups) * ncols + c];
-            const double v3 = partial[(size_t)(b + 3 * groups) * ncols + c];
-            const double v4 = partial[(size_t)(b + 4 * groups) * ncols + c];
-            const double v5 = partial[(size_t)(b + 5 * groups) * ncols + c];
-            const double v6 = partial[(size_t)(b + 6 * groups) * ncols + c];
-            const double v7 = partial[(size_t)(b + 7 * groups) * ncols + c];
-            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
+        for (; b + 3 * groups < nblk; b += 4 * groups) {
+            const double v0 = base[(size_t)(b + 0 * groups) * 2 * H], v1 = base[(size_t)(b + 1 * groups) * 2 * H];
+            const double v2 = base[(size_t)(b + 2 * groups) * 2 * H], v3 = base[(size_t)(b + 3 * groups) * 2 * H];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
         }
-        for (; b < nblk; b += groups) s0 += partial[(size_t)b * ncols + c];
-        s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
-        lds[g * ncols + c] = s;
+        for (; b < nblk; b += groups) s0 += base[(size_t)b * 2 * H];
     }
+    lds[g * NC + cc] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (tid < ncols) {
+    if (tid < NC) {
         double t = 0.0;
-        for (int gg = 0; gg < groups; ++gg) t += lds[gg * ncols + tid];
-        result[tid] = t;
+        for (int gg = 0; gg < groups; ++gg) t += lds[gg * NC + tid];
+        tot[tid] = t;
     }
     __syncthreads();
 }
@@ -56,32 +55,34 @@ __global__ void __launch_bounds__(1024) gnm_bn_finalize_kernel(
     float momentum, float eps, int training, int update_running, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     __shared__ double lds[1024];
-    __shared__ double tot[256];
+    __shared__ double tot[2 * kFinCols];
     const int tid = threadIdx.x;
-    if (training) reduce_partials_1024(partial, nblk, 2 * H, lds, tot);
-    if (tid < H) {
+    const int c0 = blockIdx.x * kFinCols;
+    if (training) reduce_partials_slice(partial, nblk, H, c0, lds, tot);
+    const int c = c0 + tid;
+    if (tid < kFinCols && c < H) {
         double mean, var;
         if (training) {
             mean = tot[tid] / (double)nrows;
-            var = tot[H + tid] / (double)nrows - mean * mean;
+            var = tot[kFinCols + tid] / (double)nrows - mean * mean;
             if (var < 0.0) var = 0.0;
             if (update_running) {
                 const double unbiased = nrows > 1 ? var * ((double)nrows / (double)(nrows - 1)) : var;
-                running_mean[tid] = (float)((1.0 - (double)momentum) * (double)running_mean[tid] + (double)momentum * mean);
-                running_var[tid] = (float)((1.0 - (double)momentum) * (double)running_var[tid] + (double)momentum * unbiased);
+                running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * mean);
+                running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unbiased);
             }
         } else {
-            mean = (double)running_mean[tid];
-            var = (double)running_var[tid];
+            mean = (double)running_mean[c];
+            var = (double)running_var[c];
         }
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[tid] * rstd;
-        scale[tid] = sc;
-        shift[tid] = beta[tid] - (float)mean * sc;
-        mean_out[tid] = (float)mean;
-        rstd_out[tid] = rstd;
+        const float sc = gamma[c] * rstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        mean_out[c] = (float)mean;
+        rstd_out[c] = rstd;
     }
-    if (tid == 0 && training && update_running && num_batches_tracked) *num_batches_tracked += 1;
+    if (blockIdx.x == 0 && tid == 0 && training && update_running && num_batches_tracked) *num_batches_tracked += 1;
 }
 
 extern "C" int gnm_bn_finalize(const double* stats_partial, int nblk, int H, long long nrows, const float* gamma,
@@ -90,8 +91,8 @@ extern "C" int gnm_bn_finalize(const double* stats_partial, int nblk, int H, lon
                                int update_running, float* scale, float* shift, float* mean_out, float* rstd_out,
                                void* stream) {
     if (H <= 0 || H > 128) return GNM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gnm_bn_finalize_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
-                       stats_partial, nblk, H, nrows, gamma, beta, running_mean, running_var, num_batches_tracked,
+    hipLaunchKernelGGL(gnm_bn_finalize_kernel, dim3((H + kFinCols - 1) / kFinCols), dim3(1024), 0,
+                       reinterpret_cast<hipStream_t>(stream), stats_partial, nblk, H, nrows, gamma, beta, running_mean, running_var, num_batches_tracked,
                        momentum, eps, training, update_running, scale, shift, mean_out, rstd_out);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
@@ -267,16 +268,18 @@ __global__ void __launch_bounds__(1024) gnm_bn_bwd_finalize_kernel(
     const float* __restrict__ rstd, int training, float* __restrict__ dgamma, float* __restrict__ dbeta,
     float* __restrict__ cA, float* __restrict__ m1, float* __restrict__ m2) {
     __shared__ double lds[1024];
-    __shared__ double tot[256];
+    __shared__ double tot[2 * kFinCols];
     const int tid = threadIdx.x;
-    reduce_partials_1024(partial, nblk, 2 * H, lds, tot);
-    if (tid < H) {
-        const double s1 = tot[tid], s2 = tot[H + tid];
-        if (dbeta) dbeta[tid] = (float)s1;
-        if (dgamma) dgamma[tid] = (float)s2;
-        cA[tid] = gamma[tid] * rstd[tid];
-        m1[tid] = training ? (float)(s1 / (double)nrows) : 0.f;
-        m2[tid] = training ? (float)(s2 / (double)nrows) : 0.f;
+    const int c0 = blockIdx.x * kFinCols;
+    reduce_partials_slice(partial, nblk, H, c0, lds, tot);
+    const int c = c0 + tid;
+    if (tid < kFinCols && c < H) {
+        const double s1 = tot[tid], s2 = tot[kFinCols + tid];
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dgamma) dgamma[c] = (float)s2;
+        cA[c] = gamma[c] * rstd[c];
+        m1[c] = training ? (float)(s1 / (double)nrows) : 0.f;
+        m2[c] = training ? (float)(s2 / (double)nrows) : 0.f;
     }
 }
 
@@ -284,8 +287,8 @@ extern "C" int gnm_bn_bwd_finalize(const double* partial, int nblk, int H, long 
                                    const float* rstd, int training, float* dgamma, float* dbeta, float* cA,
                                    float* m1, float* m2, void* stream) {
     if (H <= 0 || H > 128) return GNM_ERR_BAD_ARG;
-    hipLaunchKernelGGL(gnm_bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
-                       partial, nblk, H, nrows, gamma, rstd, training, dgamma, dbeta, cA, m1, m2);
+    hipLaunchKernelGGL(gnm_bn_bwd_finalize_kernel, dim3((H + kFinCols - 1) / kFinCols), dim3(1024), 0,
+                       reinterpret_cast<hipStream_t>(stream), partial, nblk, H, nrows, gamma, rstd, training, dgamma, dbeta, cA, m1, m2);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }

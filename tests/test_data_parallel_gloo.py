@@ -136,3 +136,39 @@ def test_flat_params_keep_module_semantics():
     for p in m.parameters():
         assert torch.equal(p.data.reshape(-1), fp.flat[off:off + p.numel()])
         off += p.numel()
+
+
+def test_autograd_accumulates_into_flat_buffer():
+    """loss.backward() must ADD into the flat gradient views (AccumulateGrad's in-place
+    path), otherwise the all-reduce would see zeros.  Uses the max-pooling torch path,
+    the only one that runs on CPU."""
+    from gnm.parallel import FlatParams
+    from models.graphcnn import GIN_InfoMaxReg
+    from helpers import edge_mat_of, load_case
+
+    class G:
+        pass
+
+    cfg, state, d = load_case("tiny_s1_eps1_gsum_nsum")
+    gs = []
+    for g in range(cfg["B"]):
+        o = G(); o.g = list(range(cfg["n"])); o.node_features = torch.from_numpy(d[f"feat_{g}"]); o.label = 0
+        em = edge_mat_of(d[f"und_{g}"]); o.edge_mat = torch.from_numpy(em)
+        o.neighbors = [[] for _ in range(cfg["n"])]
+        for i, j in em.T:
+            o.neighbors[int(i)].append(int(j))
+        o.max_neighbor = max(len(x) for x in o.neighbors)
+        gs.append(o)
+    torch.manual_seed(0)
+    m = GIN_InfoMaxReg(cfg["L"], cfg["m"], cfg["f0"], cfg["H"], cfg["C"], 0.0, True, "sum", "max", torch.device("cpu"))
+    fp = FlatParams(m)
+    for step in range(2):                       # second step: views must still be attached
+        fp.zero_grad()
+        c, dl = m(gs)
+        (c.sum() + dl.sum()).backward()
+        assert fp.flat_grad.abs().sum() > 0
+        off = 0
+        for p in m.parameters():
+            assert p.grad.data_ptr() == fp.flat_grad.data_ptr() + 4 * off
+            assert torch.equal(p.grad.reshape(-1), fp.flat_grad[off:off + p.numel()])
+            off += p.numel()

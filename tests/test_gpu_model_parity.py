@@ -286,3 +286,42 @@ def test_run_to_run_determinism():
         outs.append([p.grad.clone() for p in model.parameters() if p.grad is not None] + [c_logit.detach(), d_logit.detach()])
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("npool,gpool,learn_eps", [("sum", "sum", True), ("average", "average", True),
+                                                   ("sum", "average", False)])
+def test_sparse_regime_config4_vs_fp64_oracle(npool, gpool, learn_eps):
+    """BASELINE configs[3]: 1000-node k-NN (k = 20, symmetrised) graphs, hidden 128 -- the
+    [n, 128] tile does not fit LDS, so the aggregation runs as 4 feature slices of 32.
+    Whole training step against the fp64 oracle (no golden exists for this shape; the
+    oracle is the one pinned by the goldens)."""
+    from gnm import synth
+    from models.graphcnn import GIN_InfoMaxReg
+    from oracle import gin_oracle as O
+    L, m, f0, H, C, B = 3, 2, 7, 128, 2, 2
+    graphs = [synth.knn_graph(g, n=1000, k=20, f0=f0) for g in range(B)]
+    assert 25000 < graphs[0].edge_mat.shape[1] < 33000          # ~29.1k directed edges (SURVEY 8(d))
+    dev = torch.device(DEV)
+    torch.manual_seed(5)
+    model = GIN_InfoMaxReg(L, m, f0, H, C, 0.0, learn_eps, gpool, npool, dev).to(dev).train()
+    state = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    np.random.seed(4)
+    perm = np.random.permutation(B)
+    np.random.seed(4)
+    c_logit, d_logit = model(graphs)
+    N = B * 1000
+    labels = torch.tensor([g.label for g in graphs], device=dev)
+    d_labels = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev)
+    loss = torch.nn.CrossEntropyLoss()(c_logit, labels) + 0.05 * torch.nn.BCEWithLogitsLoss()(d_logit, d_labels)
+    loss.backward()
+    ob = [O.OGraph(1000, g.edge_mat.numpy(), g.node_features.numpy(), g.label) for g in graphs]
+    truth = O.OracleGIN(state, L, m, learn_eps, gpool, npool, dtype=np.float64).train_step_grads(ob, perm)
+    assert_close(c_logit.detach().cpu().numpy(), truth["c_logit"], rtol=2 * RTOL, what="c_logit")
+    assert_close(d_logit.detach().cpu().numpy(), truth["d_logit"], rtol=2 * RTOL, what="d_logit")
+    floor = 2e-2 * max(float(np.abs(v).max()) for v in truth["grads"].values())
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            assert name == "eps" and not learn_eps
+            continue
+        assert_close(p.grad.cpu().numpy(), truth["grads"][name].reshape(p.shape), rtol=TRUE_SHAPE_GRAD_RTOL,
+                     what=name, floor=floor)

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(1024) k(float* out, const unsigned* idx, int i
     float s0 = 0, s1 = 1, s2 = 2, s3 = 3, s4 = 4, s5 = 5, s6 = 6, s7 = 7;
     unsigned u0 = valb, u1 = valb + 1, u2 = valb + 2, u3 = valb + 3;
     double d0 = 1.0, d1 = 2.0, d2 = 3.0, d3 = 4.0, dk = 1e-300;
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < ((MODE == 6 || MODE == 7) ? 0 : iters); ++it) {
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -66,6 +66,30 @@ __global__ void __launch_bounds__(1024) k(float* out, const unsigned* idx, int i
             valb ^= 256;   // change rows a little so nothing is hoisted
         }
     }
+    if constexpr (MODE == 6 || MODE == 7) {
+        constexpr int NB = MODE == 6 ? 8 : 16;
+        f32x4 A[NB], Bf[NB];
+#define RDX(S) (*(lds_cf4p)(uintptr_t)(bc<S>(valb) + subb))
+#define FILL8(X, O) X[O+0] = RDX(0); X[O+1] = RDX(1); X[O+2] = RDX(2); X[O+3] = RDX(3); X[O+4] = RDX(4); X[O+5] = RDX(5); X[O+6] = RDX(6); X[O+7] = RDX(7);
+#define FILL8B(X, O) X[O+0] = RDX(8); X[O+1] = RDX(9); X[O+2] = RDX(10); X[O+3] = RDX(11); X[O+4] = RDX(12); X[O+5] = RDX(13); X[O+6] = RDX(14); X[O+7] = RDX(15);
+        if constexpr (NB == 8) { FILL8(A, 0) } else { FILL8(A, 0) FILL8B(A, 8) }
+        const int n2 = (MODE == 6) ? iters : iters / 2;   // same number of steps as the 16/iter modes
+        for (int it = 0; it < n2; ++it) {
+            valb ^= 256;
+            if constexpr (NB == 8) { FILL8B(Bf, 0) } else { FILL8(Bf, 0) FILL8B(Bf, 8) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NB; j += 4) { a0 += (A[j] + A[j+1]) + (A[j+2] + A[j+3]); }
+            __builtin_amdgcn_sched_barrier(0);
+            valb ^= 256;
+            if constexpr (NB == 8) { FILL8(A, 0) } else { FILL8(A, 0) FILL8B(A, 8) }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NB; j += 4) { a1 += (Bf[j] + Bf[j+1]) + (Bf[j+2] + Bf[j+3]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        a2 += A[0] + A[NB-1];
+    }
     f32x4 t = a0 + a1 + a2 + a3;
     out[blockIdx.x * blockDim.x + threadIdx.x] = t[0] + t[1] + t[2] + t[3] + s0 + s1 + s2 + s3 + s4 + s5 + s6 + s7 + (float)(u0 + u1 + u2 + u3) + (float)(d0 + d1 + d2 + d3);
 }
@@ -102,6 +126,8 @@ int main() {
         run<2>("v_add_u32_dpp newbcast (16/iter)", th, it, 16, out, idx);
         run<3>("ds_read_b128 (16/iter)", th, it, 16, out, idx);
         run<4>("gather mix per step (16/iter)", th, it, 16, out, idx);
+        run<6>("gather mix, 8+8 double-buffered", th, it, 16, out, idx);
+        run<7>("gather mix, 16+16 double-buffered", th, it, 16, out, idx);
     }
     return 0;
 }
