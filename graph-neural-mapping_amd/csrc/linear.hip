@@ -781,6 +781,280 @@ __global__ void gnm_reduce_partials_kernel(const float* __restrict__ partial, in
     }
 }
 
+// ------------------------------------------------------------------------------
+// Fused backward of one Linear that is followed by a train/eval BatchNorm (mlp.py:48,
+// graphcnn.py:163): replaces  gnm_bn_bwd_apply -> gnm_linear_wgrad -> gnm_linear_fwd(dgrad)
+// (10 passes over [N,H] arrays) by ONE pass that reads G (masked incoming gradient), Z (this
+// Linear's output = the BatchNorm input) and X (this Linear's input) and writes dX:
+//     dZ = cA * (G - m1 - xhat * m2),  xhat = (Z - mean) * rstd        (BatchNorm backward)
+//     dX = dZ W                                                          (64 MFMAs per 32 rows)
+//     dW = dZ^T f(X),  db = sum dZ                                       (64 MFMAs per 32 rows)
+// The dZ tile lives only in the wave's LDS staging image: dgrad reads it row-wise
+// (ds_read_b128 A fragments), wgrad column-wise (ds_read_b32, lane = column).  f(X) operands
+// come straight from global memory (128 B per half-wave), all loads of a tile are issued
+// before its MFMAs.  K, H in {32, 64} (accumulators: 32*K/32 + 16*(H/32)*(K/32) registers).
+// ------------------------------------------------------------------------------
+struct LbArgs {
+    const float* G; const float* Z; const float* X; const float* W;
+    const float* mean; const float* rstd; const float* cA; const float* m1; const float* m2;
+    const float* pro_scale; const float* pro_shift;
+    float* dA; float* partial;
+    int ldg, ldz, ldx, ldw, lda;
+    int N, K, H;
+    int pro_relu;
+};
+
+template <int KT, int HT>
+__global__ void __launch_bounds__(256) gnm_linear_bwd_fused_kernel(const LbArgs p) {
+    constexpr int KP = KT * 32, HP = HT * 32;
+    constexpr int XS = (KP > HP ? KP : HP) + 4;
+    constexpr int H4 = HP / 4;                    // float4 per dZ row
+    constexpr int NLD = (32 * H4) / 64;           // float4 loads per lane for a [32][HP] tile
+    constexpr int RSTEP = 64 / H4;
+    constexpr int KH = HP / 2;                    // dgrad MFMA steps (contraction over H)
+    constexpr int O4 = KP / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Wt = reinterpret_cast<float*>(smem);                   // [HP][KP]: W itself (contraction index first)
+    float* Xs_all = Wt + (size_t)HP * KP;                         // [4][32][XS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float* Xs = Xs_all + wave * 32 * XS;
+    for (int idx = tid; idx < HP * KP; idx += 256) {
+        const int hh = idx / KP, k = idx - hh * KP;
+        Wt[idx] = p.W[(size_t)hh * p.ldw + k];
+    }
+    __syncthreads();
+
+    const int c4 = lane % H4, lrow0 = lane / H4;
+    const float4 mu = *reinterpret_cast<const float4*>(p.mean + 4 * c4);
+    const float4 rs = *reinterpret_cast<const float4*>(p.rstd + 4 * c4);
+    const float4 ca = *reinterpret_cast<const float4*>(p.cA + 4 * c4);
+    const float4 a1 = *reinterpret_cast<const float4*>(p.m1 + 4 * c4);
+    const float4 a2 = *reinterpret_cast<const float4*>(p.m2 + 4 * c4);
+    float psc[KT], psh[KT];
+#pragma unroll
+    for (int b = 0; b < KT; ++b) {
+        psc[b] = p.pro_scale ? p.pro_scale[32 * b + i] : 1.f;
+        psh[b] = p.pro_scale ? p.pro_shift[32 * b + i] : 0.f;
+    }
+    f32x16 wacc[HT][KT];                          // dW accumulators
+#pragma unroll
+    for (int a = 0; a < HT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wacc[a][b][r] = 0.f;
+    float dbacc[HT];
+#pragma unroll
+    for (int a = 0; a < HT; ++a) dbacc[a] = 0.f;
+
+    const int ntiles = (p.N + 31) / 32;
+    const int nlast = p.N - 1;
+    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+        const int r0 = t * 32;
+        // ---- all global loads of the tile first -------------------------------------
+        float4 g4[NLD], z4[NLD];
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int grow = min(r0 + lrow0 + j * RSTEP, nlast);
+            g4[j] = *reinterpret_cast<const float4*>(p.G + (size_t)grow * p.ldg + 4 * c4);
+            z4[j] = *reinterpret_cast<const float4*>(p.Z + (size_t)grow * p.ldz + 4 * c4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dZ tile -> LDS (rows past N are zero: they must not contribute) ----------
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int lrow = lrow0 + j * RSTEP;
+            float4 d;
+            d.x = ca.x * (g4[j].x - a1.x - (z4[j].x - mu.x) * rs.x * a2.x);
+            d.y = ca.y * (g4[j].y - a1.y - (z4[j].y - mu.y) * rs.y * a2.y);
+            d.z = ca.z * (g4[j].z - a1.z - (z4[j].z - mu.z) * rs.z * a2.z);
+            d.w = ca.w * (g4[j].w - a1.w - (z4[j].w - mu.w) * rs.w * a2.w);
+            if (r0 + lrow >= p.N) d = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Xs + lrow * XS + 4 * c4) = d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // f(X) operands of the wgrad product: issued now (the G/Z registers are dead), they are in
+        // flight during the 64 dgrad MFMAs below
+        float xv[16][KT];                         // X[r0 + 2s + h][32b + i]
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int grow = min(r0 + 2 * s + h, nlast);
+#pragma unroll
+            for (int b = 0; b < KT; ++b) xv[s][b] = p.X[(size_t)grow * p.ldx + 32 * b + i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dX = dZ W ------------------------------------------------------------------
+        f32x16 dacc[KT];
+        if (p.dA) {
+            float a[KH];
+#pragma unroll
+            for (int j = 0; j < KH / 4; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 4 * j);
+                a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+            }
+#pragma unroll
+            for (int c = 0; c < KT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[c][r] = 0.f;
+            const float* wrow = Wt + (size_t)(KH * h) * KP + i;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) {
+#pragma unroll
+                for (int c = 0; c < KT; ++c)
+                    dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wrow[s * KP + 32 * c], dacc[c], 0, 0, 0);
+            }
+        }
+        // ---- dW += dZ^T f(X), db += column sums of dZ -----------------------------------
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float av[HT];
+#pragma unroll
+            for (int a = 0; a < HT; ++a) av[a] = Xs[(2 * s + h) * XS + 32 * a + i];
+#pragma unroll
+            for (int b = 0; b < KT; ++b) {
+                float x = xv[s][b];
+                if (p.pro_scale) {
+                    x = x * psc[b] + psh[b];
+                    if (p.pro_relu) x = fmaxf(x, 0.f);
+                }
+                xv[s][b] = x;
+            }
+#pragma unroll
+            for (int a = 0; a < HT; ++a) {
+                dbacc[a] += av[a];
+#pragma unroll
+                for (int b = 0; b < KT; ++b)
+                    wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], xv[s][b], wacc[a][b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // everyone is done reading the dZ image
+        // ---- store dX through the staging image (16-B row-contiguous stores) ---------------
+        if (p.dA) {
+#pragma unroll
+            for (int c = 0; c < KT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Xs[((r & 3) + 8 * (r >> 2) + 4 * h) * XS + 32 * c + i] = dacc[c][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int idx = lane; idx < 32 * O4; idx += 64) {
+                const int row = idx / O4, oc = idx - row * O4;
+                if (r0 + row < p.N)
+                    *reinterpret_cast<float4*>(p.dA + (size_t)(r0 + row) * p.lda + 4 * oc) =
+                        *reinterpret_cast<const float4*>(Xs + row * XS + 4 * oc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- combine the 4 waves' dW / db in a fixed order: one partial per block -------------
+    __syncthreads();
+    constexpr int TILE = 16 * 64;
+    float* dump = reinterpret_cast<float*>(smem);                 // [4][HT*KT][16][64] + [4][HT][64]
+    float* mine = dump + (size_t)wave * HT * KT * TILE;
+#pragma unroll
+    for (int a = 0; a < HT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(a * KT + b) * TILE + r * 64 + lane] = wacc[a][b][r];
+    float* dbdump = dump + (size_t)4 * HT * KT * TILE;
+#pragma unroll
+    for (int a = 0; a < HT; ++a) dbdump[(wave * HT + a) * 64 + lane] = dbacc[a];
+    __syncthreads();
+    float* out = p.partial + (size_t)blockIdx.x * ((size_t)p.H * p.K + p.H);
+    for (int idx = tid; idx < HT * KT * TILE; idx += 256) {
+        const int ab = idx / TILE;
+        const int rl = idx - ab * TILE;
+        const int r = rl >> 6, ln = rl & 63;
+        const int a = ab / KT, b = ab - a * KT;
+        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int col = 32 * b + (ln & 31);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += dump[(size_t)w * HT * KT * TILE + idx];
+        out[(size_t)row * p.K + col] = sum;
+    }
+    for (int idx = tid; idx < HT * 32; idx += 256) {
+        const int a = idx >> 5, ii = idx & 31;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += dbdump[(w * HT + a) * 64 + ii] + dbdump[(w * HT + a) * 64 + 32 + ii];
+        out[(size_t)p.H * p.K + 32 * a + ii] = sum;
+    }
+}
+
+template <int KT, int HT>
+static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
+    constexpr int KP = KT * 32, HP = HT * 32;
+    constexpr int XS = (KP > HP ? KP : HP) + 4;
+    size_t lds = (size_t)HP * KP * 4 + (size_t)4 * 32 * XS * 4;
+    const size_t dump = ((size_t)4 * HT * KT * 1024 + (size_t)4 * HT * 64) * 4;
+    if (dump > lds) lds = dump;
+    static bool configured = false;
+    if (!configured) {
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_linear_bwd_fused_kernel<KT, HT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        configured = true;
+    }
+    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT>), dim3(grid), dim3(256), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+extern "C" int gnm_linear_bwd_grid(int N) {
+    int g = ((N + 31) / 32 + 3) / 4;
+    if (g > 512) g = 512;
+    return g < 1 ? 1 : g;
+}
+extern "C" long long gnm_linear_bwd_workspace_floats(int N, int H, int K) {
+    return (long long)gnm_linear_bwd_grid(N) * ((long long)H * K + H);
+}
+
+// Returns GNM_ERR_UNSUPPORTED (and launches nothing) when the shape/alignment is not
+// eligible; the caller then uses gnm_bn_bwd_apply + gnm_linear_wgrad + gnm_linear_fwd.
+extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int ldz, const float* mean,
+                                    const float* rstd, const float* cA, const float* m1, const float* m2,
+                                    const float* X, int ldx, const float* pro_scale, const float* pro_shift,
+                                    int pro_relu, const float* W, int ldw, float* dA, int lda, float* dW, int lddw,
+                                    float* db, float* workspace, int N, int K, int H, void* stream) {
+    if (N <= 0) return GNM_ERR_UNSUPPORTED;
+    if ((K != 32 && K != 64) || (H != 32 && H != 64)) return GNM_ERR_UNSUPPORTED;
+    if ((ldg & 3) || (ldz & 3) || (dA && (lda & 3)) || getenv("GNM_LIN_GENERIC")) return GNM_ERR_UNSUPPORTED;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Z) |
+                         reinterpret_cast<uintptr_t>(dA) | reinterpret_cast<uintptr_t>(mean) |
+                         reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(cA) |
+                         reinterpret_cast<uintptr_t>(m1) | reinterpret_cast<uintptr_t>(m2);
+    if (al & 15) return GNM_ERR_UNSUPPORTED;
+    LbArgs a;
+    a.G = G; a.Z = Z; a.X = X; a.W = W; a.mean = mean; a.rstd = rstd; a.cA = cA; a.m1 = m1; a.m2 = m2;
+    a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dA = dA; a.partial = workspace;
+    a.ldg = ldg; a.ldz = ldz; a.ldx = ldx; a.ldw = ldw; a.lda = lda; a.N = N; a.K = K; a.H = H; a.pro_relu = pro_relu;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = gnm_linear_bwd_grid(N);
+    int rc = GNM_ERR_UNSUPPORTED;
+    const int KT = K / 32, HT = H / 32;
+    if (KT == 1 && HT == 1) rc = launch_lb<1, 1>(a, grid, s);
+    if (KT == 2 && HT == 1) rc = launch_lb<2, 1>(a, grid, s);
+    if (KT == 1 && HT == 2) rc = launch_lb<1, 2>(a, grid, s);
+    if (KT == 2 && HT == 2) rc = launch_lb<2, 2>(a, grid, s);
+    if (rc != GNM_OK) return rc;
+    const long long stride = (long long)H * K + H;
+    const int count = H * K + H;
+    hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 255) / 256), dim3(256), 0, s, workspace, grid, stride,
+                       H, K, 0, dW, lddw, db);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 // dW[H,K] (row-major, ld = ldw) and db[H] from dZ[N,H] and f(X)[N,K].  `workspace`
 // must hold gnm_wgrad_workspace_floats(N,H,K) floats.
 extern "C" int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ldx, int N, int H, int K,

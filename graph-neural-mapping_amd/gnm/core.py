@@ -327,30 +327,42 @@ class GinInfoMaxFn(torch.autograd.Function):
                                               dbeta.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), st),
                       "gnm_bn_bwd_finalize")
                 grads[bn + ".weight"], grads[bn + ".bias"] = dgamma, dbeta
-                check(lib.gnm_bn_bwd_apply(G.data_ptr(), G.stride(0), sv.z.data_ptr(), sv.z.stride(0),
-                                           sv.mean.data_ptr(), sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(),
-                                           m2.data_ptr(), G.data_ptr(), G.stride(0), N, Hk, st), "gnm_bn_bwd_apply")
-                dZ = G
                 wname = f"mlps.{l}.linear" if m == 1 else f"mlps.{l}.linears.{k}"
                 W = P[wname + ".weight"]
                 dW = torch.empty_like(W)
                 db = torch.empty(Hk, **f32)
-                ws = torch.empty(int(lib.gnm_wgrad_workspace_floats(N, Hk, K)), **f32)
-                with _timed("wgrad_K%d_H%d" % (K, Hk), N=N, K=K, H=Hk):
-                    check(lib.gnm_linear_wgrad(dZ.data_ptr(), dZ.stride(0), sv.x_in.data_ptr(), sv.x_in.stride(0), N,
-                                               Hk, K, ptr(sv.pro[0]) if sv.pro else None,
-                                               ptr(sv.pro[1]) if sv.pro else None, 1 if sv.pro else 0,
-                                               dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), st),
-                          "gnm_linear_wgrad")
-                grads[wname + ".weight"], grads[wname + ".bias"] = dW, db
                 # dX of this Linear: always for inner Linears; for the first one only when the
                 # aggregation backward below has a consumer (a lower layer, dX, or d eps[l])
-                if k > 0 or l > 0 or need_dx or spec.learn_eps:
-                    dA = torch.empty((N, K), **f32)                            # dX = dZ W
-                    _linear_wide(dZ, W, 1, None, dA, N, Hk, K, None, None)
-                    incoming = dA
+                need_dA = k > 0 or l > 0 or need_dx or spec.learn_eps
+                dA = torch.empty((N, K), **f32) if need_dA else None
+                # one fused pass (BatchNorm-backward apply + dX + dW + db) when the shape is eligible
+                ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, Hk, K)), **f32)
+                with _timed("linbwd_K%d_H%d" % (K, Hk), N=N, K=K, H=Hk):
+                    rc = lib.gnm_linear_bwd_fused(
+                        G.data_ptr(), G.stride(0), sv.z.data_ptr(), sv.z.stride(0), sv.mean.data_ptr(),
+                        sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), sv.x_in.data_ptr(),
+                        sv.x_in.stride(0), ptr(sv.pro[0]) if sv.pro else None, ptr(sv.pro[1]) if sv.pro else None,
+                        1 if sv.pro else 0, W.data_ptr(), W.stride(0), ptr(dA), dA.stride(0) if need_dA else 0,
+                        dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), N, K, Hk, st)
+                if rc == -2:        # GNM_ERR_UNSUPPORTED: generic three-kernel path
+                    check(lib.gnm_bn_bwd_apply(G.data_ptr(), G.stride(0), sv.z.data_ptr(), sv.z.stride(0),
+                                               sv.mean.data_ptr(), sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(),
+                                               m2.data_ptr(), G.data_ptr(), G.stride(0), N, Hk, st),
+                          "gnm_bn_bwd_apply")
+                    dZ = G
+                    ws = torch.empty(int(lib.gnm_wgrad_workspace_floats(N, Hk, K)), **f32)
+                    with _timed("wgrad_K%d_H%d" % (K, Hk), N=N, K=K, H=Hk):
+                        check(lib.gnm_linear_wgrad(dZ.data_ptr(), dZ.stride(0), sv.x_in.data_ptr(),
+                                                   sv.x_in.stride(0), N, Hk, K, ptr(sv.pro[0]) if sv.pro else None,
+                                                   ptr(sv.pro[1]) if sv.pro else None, 1 if sv.pro else 0,
+                                                   dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), st),
+                              "gnm_linear_wgrad")
+                    if need_dA:
+                        _linear_wide(dZ, W, 1, None, dA, N, Hk, K, None, None)      # dX = dZ W
                 else:
-                    incoming = None
+                    check(rc, "gnm_linear_bwd_fused")
+                grads[wname + ".weight"], grads[wname + ".bias"] = dW, db
+                incoming = dA
             # aggregation backward: d h_{l-1} = A^T (dpooled [/deg]) + (1+eps) dpooled ; d eps[l]
             if incoming is not None:
                 dpooled = incoming

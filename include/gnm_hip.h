@@ -91,6 +91,20 @@ int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ldx, int N, i
                      const float* pro_scale, const float* pro_shift, int pro_relu, float* dW, int ldw, float* db,
                      float* workspace, void* stream);
 
+/* Fused backward of a Linear followed by BatchNorm (the autograd of mlp.py:48 / graphcnn.py:162-163):
+ * dZ = cA*(G - m1 - xhat*m2) formed on the fly from G (output of gnm_bn_relu_bwd_stats) and Z,
+ * then dX = dZ W (into dA, may be null), dW = dZ^T f(X), db = sum dZ -- one pass instead of
+ * gnm_bn_bwd_apply + gnm_linear_wgrad + gnm_linear_fwd(w_kmajor=1).  Eligible for K, H in {32, 64} and
+ * 16-B aligned rows; otherwise returns GNM_ERR_UNSUPPORTED without launching anything.
+ * workspace: gnm_linear_bwd_workspace_floats(N, H, K) floats. */
+int gnm_linear_bwd_grid(int N);
+long long gnm_linear_bwd_workspace_floats(int N, int H, int K);
+int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int ldz, const float* mean, const float* rstd,
+                         const float* cA, const float* m1, const float* m2, const float* X, int ldx,
+                         const float* pro_scale, const float* pro_shift, int pro_relu, const float* W, int ldw,
+                         float* dA, int lda, float* dW, int lddw, float* db, float* workspace, int N, int K, int H,
+                         void* stream);
+
 /* ---- BatchNorm1d + ReLU + readout (mlp.py:38,48; graphcnn.py:51,163-166,187-190,228-229) */
 int gnm_bn_finalize(const double* stats_partial, int nblk, int H, long long nrows, const float* gamma,
                     const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,

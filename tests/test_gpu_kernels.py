@@ -174,6 +174,48 @@ def test_linear_forward_stats_and_grads(N, K, H, pro):
     assert_close(db.cpu().numpy(), dZ.astype(np.float64).sum(0), rtol=TOL, what="bias grad")
 
 
+@pytest.mark.parametrize("N,K,H", [(1000, 64, 64), (33, 64, 64), (4099, 32, 64), (257, 64, 32), (700, 32, 32)])
+@pytest.mark.parametrize("pro,want_dx", [(True, True), (False, True), (True, False)])
+def test_linear_backward_fused(N, K, H, pro, want_dx):
+    """gnm_linear_bwd_fused = BatchNorm-backward apply + dX + dW + db in one pass, vs the
+    oracle's bn_bwd formula and plain fp64 products."""
+    from gnm._cabi import check, lib
+    rng = np.random.default_rng(N + 17 * K + H)
+    G = rng.standard_normal((N, H)).astype(np.float32)
+    Z = (rng.standard_normal((N, H)) * 1.5 + 0.5).astype(np.float32)
+    X = rng.standard_normal((N, K)).astype(np.float32)
+    W = (rng.standard_normal((H, K)) / np.sqrt(K)).astype(np.float32)
+    mean, rstd = Z.mean(0).astype(np.float32), (1 / np.sqrt(Z.var(0) + 1e-5)).astype(np.float32)
+    cA = rng.uniform(0.5, 1.5, H).astype(np.float32)
+    m1 = (G.mean(0)).astype(np.float32)
+    m2 = rng.standard_normal(H).astype(np.float32) * 0.1
+    sc, sh = rng.uniform(0.5, 1.5, K).astype(np.float32), rng.standard_normal(K).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    Gd, Zd, Xd, Wd, md, rd, cd, m1d, m2d, scd, shd = map(t, (G, Z, X, W, mean, rstd, cA, m1, m2, sc, sh))
+    dA = torch.full((N, K), float("nan"), device=DEV) if want_dx else None
+    dW = torch.full((H, K), float("nan"), device=DEV)
+    db = torch.full((H,), float("nan"), device=DEV)
+    ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, H, K)), device=DEV)
+    check(lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Zd.data_ptr(), H, md.data_ptr(), rd.data_ptr(), cd.data_ptr(),
+                                   m1d.data_ptr(), m2d.data_ptr(), Xd.data_ptr(), K, scd.data_ptr() if pro else None,
+                                   shd.data_ptr() if pro else None, 1 if pro else 0, Wd.data_ptr(), K,
+                                   dA.data_ptr() if want_dx else None, K, dW.data_ptr(), K, db.data_ptr(),
+                                   ws.data_ptr(), N, K, H, _stream()), "linear_bwd_fused")
+    f64 = np.float64
+    xhat = (Z.astype(f64) - mean) * rstd
+    dZ = cA.astype(f64) * (G.astype(f64) - m1 - xhat * m2)
+    Xe = np.maximum(X * sc + sh, 0).astype(f64) if pro else X.astype(f64)
+    if want_dx:
+        assert_close(dA.cpu().numpy(), dZ @ W.astype(f64), rtol=TOL, what="dX")
+    assert_close(dW.cpu().numpy(), dZ.T @ Xe, rtol=TOL, what="dW")
+    # db is a cancelling sum here (G - mean(G) sums to ~0): bound it by fp32 eps x sum |dZ|
+    assert_close(db.cpu().numpy(), dZ.sum(0), rtol=TOL, what="db", floor=1e-2 * np.abs(dZ).sum(0).max())
+    # ineligible shapes are refused, not mis-computed
+    assert lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Zd.data_ptr(), H, md.data_ptr(), rd.data_ptr(), cd.data_ptr(),
+                                    m1d.data_ptr(), m2d.data_ptr(), Xd.data_ptr(), K, None, None, 0, Wd.data_ptr(), K,
+                                    None, K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, 7, H, _stream()) == -2
+
+
 @pytest.mark.parametrize("sizes,H", [([40, 40, 40], 64), ([13, 50, 7], 32), ([300, 300], 128), ([1], 64)])
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("average", [0, 1])
