@@ -89,8 +89,13 @@ def main():
     ap.add_argument("--layers", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
                     help="c2: 400-node dense-FC graphs, hidden 64 (headline); c4: 1000-node kNN k=20, hidden 128")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step from a captured hipGraph (auto: when --gpus > 1, where the host launch "
+                         "cost would otherwise bound the step; the N=1 run stays eager so per-kernel HIP events exist)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true",
+                    help="HIP events around every launch (default: only the two kernels the rooflines are quoted on)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,19 +148,37 @@ def main():
     N = batches[0][0].N
     d_labels = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev)   # main.py:32, sized by node count
 
+    def loss_fn(c_logit, d_logit, lab):
+        return F.cross_entropy(c_logit, lab) + 0.05 * F.binary_cross_entropy_with_logits(d_logit, d_labels)
+
+    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    captured = None
+    if use_graph:
+        from gnm.graphs import CapturedTrainStep
+        try:
+            captured = CapturedTrainStep(model, batches[0][0], loss_fn, zero_grad=dp.zero_grad)
+        except Exception as e:                      # capture is an optimisation: fall back to eager launches
+            print("hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            captured = None
+            dp.fp.zero_grad()
+    perms = [np.random.permutation(B) for _ in range(nsteps)]     # graphcnn.py:199, one draw per forward
+
     def step(i):
         bt, lab = batches[i]
-        dp.zero_grad()
-        c_logit, d_logit = model.forward_batch(bt)
-        loss = F.cross_entropy(c_logit, lab) + 0.05 * F.binary_cross_entropy_with_logits(d_logit, d_labels)
-        loss.backward()
+        if captured is not None:
+            loss = captured.run(bt, lab, perms[i])
+        else:
+            dp.zero_grad()
+            c_logit, d_logit = model.forward_batch(bt, perm=perms[i])
+            loss = loss_fn(c_logit, d_logit, lab)
+            loss.backward()
         dp.allreduce_gradients()
         return loss
 
     for i in range(args.warmup):
         step(i)
-    if not args.no_kernel_timer:
-        core.TIMER = core.KernelTimer()
+    if not args.no_kernel_timer and captured is None:
+        core.TIMER = core.KernelTimer(None if args.time_all_kernels else ("agg_fwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -195,6 +218,7 @@ def main():
                        "pool_graphs_per_gpu": pool_n, "parallelism": "dp%d" % world},
             "final_loss": loss_val, "setup_seconds": round(t_gen, 1),
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
+            "launch_mode": "hipGraph replay" if captured is not None else "eager",
         }
         roof, roof_mlp = None, None
         if timer is not None:

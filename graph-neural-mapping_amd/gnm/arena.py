@@ -191,3 +191,34 @@ class GraphArena:
                                        out[0].ctypes.data, out[1].ctypes.data)
         assert k == nnz, (k, nnz)
         return out[:, :nnz]
+
+
+class StaticBatch:
+    """A Batch whose device tensors keep their addresses: load(batch) copies another
+    batch's descriptors into them.  What a captured hipGraph of the training step reads
+    (gnm/graphs.py); shapes (B, N, n_max) are fixed at construction."""
+
+    def __init__(self, template):
+        b = Batch()
+        for f in ("B", "N", "n_max", "n_min", "arena", "symmetric", "node_off_host"):
+            setattr(b, f, getattr(template, f))
+        b.node_off = template.node_off.clone()
+        b.rp_off, b.col_off = template.rp_off.clone(), template.col_off.clone()
+        b.gids = template.gids.clone()
+        if template.symmetric:
+            b.t_rp_off, b.t_col_off = b.rp_off, b.col_off
+        else:
+            b.t_rp_off, b.t_col_off = template.t_rp_off.clone(), template.t_col_off.clone()
+        self.batch = b
+
+    def load(self, other):
+        b = self.batch
+        if (other.B, other.N, other.n_max, other.n_min, other.symmetric) != (b.B, b.N, b.n_max, b.n_min, b.symmetric):
+            raise ValueError("StaticBatch.load: batch shape differs from the captured one")
+        b.node_off.copy_(other.node_off, non_blocking=True)
+        b.rp_off.copy_(other.rp_off, non_blocking=True)
+        b.col_off.copy_(other.col_off, non_blocking=True)
+        b.gids.copy_(other.gids, non_blocking=True)
+        if not b.symmetric:
+            b.t_rp_off.copy_(other.t_rp_off, non_blocking=True)
+            b.t_col_off.copy_(other.t_col_off, non_blocking=True)

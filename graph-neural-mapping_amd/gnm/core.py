@@ -49,8 +49,9 @@ class KernelTimer:
     launched on (torch's current stream).  bench.py turns it on for the timed region to
     compute the roofline figures; it is off (None) otherwise."""
 
-    def __init__(self):
+    def __init__(self, prefixes=None):
         self.records = []          # (name, meta, start_event, end_event)
+        self.prefixes = tuple(prefixes) if prefixes else None   # only time launches whose tag starts with one
 
     def summary(self):
         """name -> (count, mean ms, meta of the first record); call after a synchronize."""
@@ -69,13 +70,14 @@ class _timed:
         self.name, self.meta = name, meta
 
     def __enter__(self):
-        if TIMER is not None:
+        self.on = TIMER is not None and (TIMER.prefixes is None or self.name.startswith(TIMER.prefixes))
+        if self.on:
             self.a = torch.cuda.Event(enable_timing=True)
             self.b = torch.cuda.Event(enable_timing=True)
             self.a.record()
 
     def __exit__(self, *exc):
-        if TIMER is not None:
+        if self.on and TIMER is not None:
             self.b.record()
             TIMER.records.append((self.name, self.meta, self.a, self.b))
         return False
@@ -229,7 +231,10 @@ class GinInfoMaxFn(torch.autograd.Function):
             c = torch.sigmoid(g_f)                                            # graphcnn.py:239
             Wd = P["disc.f_k.weight"][0]
             U = c @ Wd.t()                                                    # U[g] = W c_g
-            perm_rows = torch.as_tensor(perm, dtype=torch.int32).to(X.device)  # row index = perm[g] (:198-201,242)
+            if torch.is_tensor(perm) and perm.is_cuda:      # graph-capture safe: already on the device
+                perm_rows = perm.to(torch.int32)
+            else:
+                perm_rows = torch.as_tensor(perm, dtype=torch.int32).to(X.device)  # row index = perm[g] (:198-201,242)
             d_logit = torch.empty((2 * N, 1), dtype=torch.float32, device=X.device)
             check(lib.gnm_disc_score_fwd(_hptr_array(hidden), hidden[0].stride(0), L, H, U.data_ptr(), U.stride(0),
                                          perm_rows.data_ptr(), P["disc.f_k.bias"].data_ptr(),
@@ -278,9 +283,8 @@ class GinInfoMaxFn(torch.autograd.Function):
             grads["disc.f_k.bias"] = dD.sum().reshape(1)
             dg_f = (dU @ Wd) * c * (1 - c)                                    # sigmoid backward
             dsc1 = dD                                                         # first N entries = d sc_1
-            inv = torch.empty(B, dtype=torch.int64)
-            inv[torch.as_tensor(ctx.perm, dtype=torch.int64)] = torch.arange(B, dtype=torch.int64)
-            inv_perm = inv.to(torch.int32).to(dev)
+            inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
+            inv_perm[ctx.perm_rows.long()] = torch.arange(B, dtype=torch.int32, device=dev)
 
         # ---- classifier ---------------------------------------------------------------
         dph = []
