@@ -49,6 +49,7 @@ struct AggArgs {
     int F;                     // valid feature width
     int nslices;
     int average, self_loop, backward;
+    int ids_in_lds;            // narrow slices: the graph's column ids are staged in LDS (max_nnz given)
     int debug;                 // tuning only (GNM_AGG16_DEBUG): 1 no id loads, 2 no epilogue/store, 4 no combine
 };
 
@@ -134,6 +135,90 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     }
     if (tid < LPR) tile[n * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // row n = zeros (padding slots)
     __syncthreads();
+
+    // ---- phase B, narrow features (FS <= 16 floats): one THREAD per (row, 16-B chunk) ------
+    // The rows are so short that the wave-cooperative scheme below spends its time in
+    // cross-lane reductions and dependent loads.  Here the graph's column ids are staged in
+    // LDS as well (p.ids_in_lds, decided by the launcher), a thread walks its row's ids 8 at a
+    // time (8 independent LDS id reads, then 8 row reads) and owns its output chunk outright.
+    if constexpr (LPR <= 4) {
+        if (p.ids_in_lds) {
+            uint16_t* ids = reinterpret_cast<uint16_t*>(smem + (size_t)(n + 1) * (FS * 4));
+            const int nnz = p.y ? rp[n] : 0;            // y == null (d-eps only): nothing to gather
+            if ((reinterpret_cast<uintptr_t>(cl) & 3) == 0) {
+                // 32-bit copies, 4 independent loads in flight per thread
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(cl);
+                uint32_t* dst = reinterpret_cast<uint32_t*>(ids);
+                const int nw = nnz >> 1;
+                int e = tid;
+                for (; e + 3 * nthreads < nw; e += 4 * nthreads) {
+                    const uint32_t v0 = src[e], v1 = src[e + nthreads], v2 = src[e + 2 * nthreads], v3 = src[e + 3 * nthreads];
+                    dst[e] = v0; dst[e + nthreads] = v1; dst[e + 2 * nthreads] = v2; dst[e + 3 * nthreads] = v3;
+                }
+                for (; e < nw; e += nthreads) dst[e] = src[e];
+                if ((nnz & 1) && tid == 0) ids[nnz - 1] = cl[nnz - 1];
+            } else {
+                for (int e = tid; e < nnz; e += nthreads) ids[e] = cl[e];
+            }
+            __syncthreads();
+            const float selfB2 = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
+            const bool vec_out2 = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+            for (int w = tid; p.y && w < n * LPR; w += nthreads) {
+                const int v = w / LPR, sub2 = w - v * LPR;
+                const int beg = rp[v], end = rp[v + 1];
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                int e = beg;
+                for (; e + 8 <= end; e += 8) {
+                    unsigned id[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) id[j] = ids[e + j];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc4(acc, tile[id[j] * LPR + sub2]);
+                }
+                for (; e < end; ++e) acc4(acc, tile[(unsigned)ids[e] * LPR + sub2]);
+                const float4 self = tile[v * LPR + sub2];
+                if (p.self_loop) acc4(acc, self);
+                if (!p.backward && p.average) {
+                    const float d = (float)(end - beg + p.self_loop);
+                    acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
+                }
+                const int cc = col0 + 4 * sub2;
+                if (!p.self_loop) {
+                    float4 sb = self;
+                    if (prescale) {
+                        const float* src = p.x + (size_t)(row0 + v) * p.ldx + cc;
+                        sb.x = (cc + 0 < p.F) ? src[0] : 0.f;
+                        sb.y = (cc + 1 < p.F) ? src[1] : 0.f;
+                        sb.z = (cc + 2 < p.F) ? src[2] : 0.f;
+                        sb.w = (cc + 3 < p.F) ? src[3] : 0.f;
+                    }
+                    acc.x += selfB2 * sb.x; acc.y += selfB2 * sb.y; acc.z += selfB2 * sb.z; acc.w += selfB2 * sb.w;
+                }
+                float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
+                if (vec_out2 && cc + 3 < p.F) {
+                    *reinterpret_cast<float4*>(dst) = acc;
+                } else {
+                    if (cc + 0 < p.F) dst[0] = acc.x;
+                    if (cc + 1 < p.F) dst[1] = acc.y;
+                    if (cc + 2 < p.F) dst[2] = acc.z;
+                    if (cc + 3 < p.F) dst[3] = acc.w;
+                }
+            }
+            if (p.deps_partial) {
+                __syncthreads();
+                double* red = reinterpret_cast<double*>(smem);
+                const double ws = wave_sum_d(dot);
+                if ((tid & 63) == 0) red[tid >> 6] = ws;
+                __syncthreads();
+                if (tid == 0) {
+                    double s2 = 0.0;
+                    for (int k = 0; k < (nthreads >> 6); ++k) s2 += red[k];
+                    p.deps_partial[blockIdx.x] = s2;
+                }
+            }
+            return;
+        }
+    }
 
     // ---- phase B: gather neighbour rows from LDS --------------------------------
     const int lane = tid & 63;
@@ -591,8 +676,15 @@ static int launch_agg16(const AggArgs& a, int B, int n_max, hipStream_t stream) 
 }
 
 template <int LPR>
-static int launch_agg(const AggArgs& a, int B, int n_max, hipStream_t stream) {
-    const size_t lds = (size_t)(n_max + 1) * LPR * 16;
+static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
+    AggArgs a = a0;
+    size_t lds = (size_t)(n_max + 1) * LPR * 16;
+    const int max_nnz = a.ids_in_lds;             // on entry: largest nnz of the batch (0 = unknown)
+    a.ids_in_lds = 0;
+    if (LPR <= 4 && max_nnz > 0 && lds + (size_t)max_nnz * 2 + 64 <= (size_t)kLdsBudget - 1024) {
+        a.ids_in_lds = 1;
+        lds += (size_t)max_nnz * 2 + 64;
+    }
     static size_t configured = 0;
     if (lds > configured) {
         GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg_kernel<LPR>),
@@ -604,6 +696,11 @@ static int launch_agg(const AggArgs& a, int B, int n_max, hipStream_t stream) {
     int threads = 1024;
     if (lds <= 20 * 1024) threads = 256;
     else if (lds <= 48 * 1024) threads = 512;
+    if (a.ids_in_lds) {                            // one thread per (row, chunk): enough threads for a whole graph
+        threads = ((n_max * LPR + 63) / 64) * 64;
+        if (threads > 1024) threads = 1024;
+        if (threads < 256) threads = 256;
+    }
     hipLaunchKernelGGL(gnm_agg_kernel<LPR>, dim3(B * a.nslices), dim3(threads), lds, stream, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
@@ -620,7 +717,7 @@ extern "C" int gnm_agg_slice_width(int F, int n_max) {
 
 extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
                        const int64_t* b_col_off, const int32_t* deg_rowptr, const int64_t* b_deg_off,
-                       const int32_t* node_off, int B, int n_max, const float* x, int ldx, float* y, int ldy,
+                       const int32_t* node_off, int B, int n_max, int nnz_max, const float* x, int ldx, float* y, int ldy,
                        int F, const float* eps, int average, int self_loop, int backward, const float* hfwd,
                        int ldh, double* deps_partial, void* stream) {
     if (B <= 0) return GNM_OK;
@@ -636,6 +733,7 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
     a.nslices = (F + fs - 1) / fs;
     a.average = average; a.self_loop = self_loop; a.backward = backward;
     a.debug = 0;
+    a.ids_in_lds = nnz_max > 0 ? nnz_max : 0;   // launch_agg turns this into the 0/1 flag
     if (const char* e = getenv("GNM_AGG16_DEBUG")) a.debug = atoi(e);
     if (deps_partial && !hfwd) return GNM_ERR_BAD_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

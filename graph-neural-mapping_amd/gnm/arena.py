@@ -44,8 +44,8 @@ class _Growable:
 class Batch:
     """What the kernels need to know about one batch of graphs (all on the device)."""
 
-    __slots__ = ("B", "N", "n_max", "n_min", "arena", "node_off", "rp_off", "col_off", "t_rp_off", "t_col_off",
-                 "gids", "node_off_host", "symmetric")
+    __slots__ = ("B", "N", "n_max", "n_min", "nnz_max", "arena", "node_off", "rp_off", "col_off", "t_rp_off",
+                 "t_col_off", "gids", "node_off_host", "symmetric")
 
     @property
     def equal_n(self):
@@ -127,6 +127,7 @@ class GraphArena:
                                     col=t(self.col_off, torch.int64), trp=t(self.t_rp_off, torch.int64),
                                     tcol=t(self.t_col_off, torch.int64), feat=t(self.feat_off, torch.int64),
                                     n_host=np.asarray(self.n, dtype=np.int64),
+                                    nnz_host=np.asarray(self.nnz, dtype=np.int64),
                                     sym_host=np.asarray(self.sym, dtype=bool))
         return self._dev_tables
 
@@ -146,6 +147,7 @@ class GraphArena:
         b.B = int(gh.shape[0])
         b.gids = gd
         b.n_max, b.n_min = int(ns.max()), int(ns.min())
+        b.nnz_max = int(tb["nnz_host"][gh].max())
         node_off_host = np.zeros(b.B + 1, dtype=np.int64)
         np.cumsum(ns, out=node_off_host[1:])
         b.node_off_host = node_off_host
@@ -200,7 +202,7 @@ class StaticBatch:
 
     def __init__(self, template):
         b = Batch()
-        for f in ("B", "N", "n_max", "n_min", "arena", "symmetric", "node_off_host"):
+        for f in ("B", "N", "n_max", "n_min", "nnz_max", "arena", "symmetric", "node_off_host"):
             setattr(b, f, getattr(template, f))
         b.node_off = template.node_off.clone()
         b.rp_off, b.col_off = template.rp_off.clone(), template.col_off.clone()
@@ -213,7 +215,8 @@ class StaticBatch:
 
     def load(self, other):
         b = self.batch
-        if (other.B, other.N, other.n_max, other.n_min, other.symmetric) != (b.B, b.N, b.n_max, b.n_min, b.symmetric):
+        if (other.B, other.N, other.n_max, other.n_min, other.symmetric) != (b.B, b.N, b.n_max, b.n_min, b.symmetric) \
+                or other.nnz_max > b.nnz_max:
             raise ValueError("StaticBatch.load: batch shape differs from the captured one")
         b.node_off.copy_(other.node_off, non_blocking=True)
         b.rp_off.copy_(other.rp_off, non_blocking=True)

@@ -104,7 +104,8 @@ def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None)
     with _timed(tag, F=F_, B=batch.B, N=batch.N):
         check(lib.gnm_agg(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), rp_off.data_ptr(), col_off.data_ptr(),
                           a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), batch.B,
-                          batch.n_max, x.data_ptr(), x.stride(0), ptr(y), y.stride(0) if y is not None else 0, F_,
+                          batch.n_max, batch.nnz_max, x.data_ptr(), x.stride(0), ptr(y),
+                          y.stride(0) if y is not None else 0, F_,
                           eps_ptr, int(spec.n_avg), int(not spec.learn_eps), int(backward), ptr(hfwd),
                           hfwd.stride(0) if hfwd is not None else 0, ptr(deps_partial), _stream()), "gnm_agg")
 

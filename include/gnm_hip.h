@@ -65,10 +65,12 @@ long long gnm_batch_coo_from_csr(const int32_t* rowptr_arena_host, const uint16_
  *                          rowptr/b_rp_off for symmetric graphs), plus, when deps_partial
  *                          is non-null, fp64 partials of d eps = sum(x * hfwd).
  * `eps` points at eps[layer] on the device (null: coefficient 1).  `self_loop` = !learn_eps.
- * n_max = largest graph of the batch.  Replaces torch.spmm at graphcnn.py:154,157,178,181. */
+ * n_max = largest graph of the batch; nnz_max = most edges of any batch graph (0 = unknown: narrow
+ * feature slices then keep their column ids in global memory instead of LDS).
+ * Replaces torch.spmm at graphcnn.py:154,157,178,181. */
 int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
             const int32_t* deg_rowptr, const int64_t* b_deg_off, const int32_t* node_off, int B, int n_max,
-            const float* x, int ldx, float* y, int ldy, int F, const float* eps, int average, int self_loop,
+            int nnz_max, const float* x, int ldx, float* y, int ldy, int F, const float* eps, int average, int self_loop,
             int backward, const float* hfwd, int ldh, double* deps_partial, void* stream);
 int gnm_agg_slice_width(int F, int n_max);          /* feature-slice width the kernel will use (0: unsupported) */
 int gnm_agg_num_partials(int F, int n_max, int B);  /* doubles written to deps_partial */
