@@ -210,19 +210,17 @@ class GinInfoMaxFn(torch.autograd.Function):
         X = X.contiguous()
         hidden, g_f, saved = encoder_forward(spec, batch, X, P, training, update_running=training)
         H = hidden[0].shape[1]
-        # classifier (graphcnn.py:224-231): tiny [B,H] x [H,C] products, torch on device
-        c_logit = None
-        masks = []
-        for l in range(L):
-            lg = F.linear(g_f[:, l * H:(l + 1) * H], P[f"linears_prediction.{l}.weight"],
-                          P[f"linears_prediction.{l}.bias"])
-            if training and dropout_p > 0:
-                mk = F.dropout(torch.ones_like(lg), dropout_p, True)
-                lg = lg * mk
-                masks.append(mk)
-            else:
-                masks.append(None)
-            c_logit = lg if c_logit is None else c_logit + lg
+        # classifier (graphcnn.py:224-231): L tiny [B,H] x [H,C] products + dropout, batched into
+        # one bmm / one dropout call on an [L,B,C] tensor (torch on device: plumbing-sized work)
+        Wp = torch.stack([P[f"linears_prediction.{l}.weight"] for l in range(L)])        # [L,C,H]
+        bp = torch.stack([P[f"linears_prediction.{l}.bias"] for l in range(L)])          # [L,C]
+        G3 = g_f.view(B, L, H).transpose(0, 1)                                           # [L,B,H] view
+        lg = torch.baddbmm(bp.unsqueeze(1), G3, Wp.transpose(1, 2))                      # [L,B,C]
+        masks = None
+        if training and dropout_p > 0:
+            masks = F.dropout(torch.ones_like(lg), dropout_p, True)                      # F.dropout at :230
+            lg = lg * masks
+        c_logit = lg.sum(0)
         d_logit = None
         c = U = perm_rows = None
         if want_disc:
@@ -242,7 +240,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                                          batch.node_off.data_ptr(), N, B, d_logit.data_ptr(), _stream()),
                   "gnm_disc_score_fwd")
         ctx.spec, ctx.batch, ctx.names, ctx.P = spec, batch, names, P
-        ctx.hidden, ctx.saved, ctx.g_f, ctx.masks = hidden, saved, g_f, masks
+        ctx.hidden, ctx.saved, ctx.g_f, ctx.masks, ctx.Wp = hidden, saved, g_f, masks, Wp
         ctx.c, ctx.U, ctx.perm_rows, ctx.perm = c, U, perm_rows, perm
         ctx.training, ctx.X = training, X
         ctx.mark_non_differentiable(g_f)
@@ -287,19 +285,25 @@ class GinInfoMaxFn(torch.autograd.Function):
             inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
             inv_perm[ctx.perm_rows.long()] = torch.arange(B, dtype=torch.int32, device=dev)
 
-        # ---- classifier ---------------------------------------------------------------
-        dph = []
-        for l in range(L):
-            d = None
-            if dC is not None:
-                dlg = dC if ctx.masks[l] is None else dC * ctx.masks[l]
-                Wp = P[f"linears_prediction.{l}.weight"]
-                grads[f"linears_prediction.{l}.weight"] = dlg.t() @ g_f[:, l * H:(l + 1) * H]
-                grads[f"linears_prediction.{l}.bias"] = dlg.sum(0)
-                d = dlg @ Wp
+        # ---- classifier (batched over the L layers) --------------------------------------
+        dph_all = None
+        G3 = g_f.view(B, L, H).transpose(0, 1)                                           # [L,B,H]
+        if dC is not None:
+            dlg = dC.unsqueeze(0).expand(L, -1, -1)
+            if ctx.masks is not None:
+                dlg = dlg * ctx.masks
+            dWp = torch.bmm(dlg.transpose(1, 2), G3)                                     # [L,C,H]
+            dbp = dlg.sum(1)                                                             # [L,C]
+            for l in range(L):
+                grads[f"linears_prediction.{l}.weight"] = dWp[l]
+                grads[f"linears_prediction.{l}.bias"] = dbp[l]
             if dg_f is not None:
-                d = dg_f[:, l * H:(l + 1) * H] if d is None else d + dg_f[:, l * H:(l + 1) * H]
-            dph.append(d.contiguous() if d is not None else None)
+                dph_all = torch.baddbmm(dg_f.view(B, L, H).transpose(0, 1), dlg, ctx.Wp)   # [L,B,H] contiguous
+            else:
+                dph_all = torch.bmm(dlg, ctx.Wp)
+        elif dg_f is not None:
+            dph_all = dg_f.view(B, L, H).transpose(0, 1).contiguous()
+        dph = [dph_all[l] if dph_all is not None else None for l in range(L)]
 
         deps = torch.zeros(L, **f32) if spec.learn_eps else None
         dH_next = None
