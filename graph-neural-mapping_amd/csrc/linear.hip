@@ -810,13 +810,17 @@ struct LbArgs {
     const float* mean; const float* rstd; const float* cA; const float* m1; const float* m2;
     const float* pro_scale; const float* pro_shift;
     float* dA; float* partial;
-    int ldg, ldz, ldx, ldw, lda;
+    // optional: dA is the gradient arriving at relu(bn_lo(sZ)) -- apply that ReLU mask to it on the way
+    // out and reduce the lower BatchNorm's backward sums (replaces gnm_bn_relu_bwd_stats for it)
+    const float* sZ; const float* s_scale; const float* s_shift; const float* s_mean; const float* s_rstd;
+    double* s_partial;         // [gridDim.x][2][K]
+    int ldg, ldz, ldx, ldw, lda, ldsz;
     int N, K, H;
     int pro_relu;
 };
 
-template <int KT, int HT>
-__global__ void __launch_bounds__(256) gnm_linear_bwd_fused_kernel(const LbArgs p) {
+template <int KT, int HT, bool STATS>
+__global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbArgs p) {   // 2 waves/SIMD: <= 256 registers
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
     constexpr int H4 = HP / 4;                    // float4 per dZ row
@@ -860,6 +864,10 @@ __global__ void __launch_bounds__(256) gnm_linear_bwd_fused_kernel(const LbArgs 
     float dbacc[HT];
 #pragma unroll
     for (int a = 0; a < HT; ++a) dbacc[a] = 0.f;
+    // lower-BatchNorm statistics of the masked dX (this lane's 16-B column chunk oc4 of the output rows)
+    constexpr int OR = 64 / O4;                   // output rows covered per pass of the store loop
+    const int oc4 = lane % O4, orow0 = lane / O4;
+    float4 ss1 = make_float4(0.f, 0.f, 0.f, 0.f), ss2 = ss1;
 
     const int ntiles = (p.N + 31) / 32;
     const int nlast = p.N - 1;
@@ -954,15 +962,78 @@ __global__ void __launch_bounds__(256) gnm_linear_bwd_fused_kernel(const LbArgs 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (STATS) {
+                __builtin_amdgcn_sched_barrier(0);   // keep these loads below the MFMA phases (register peak)
+                // coefficient vectors are (re)loaded here, not kept across the MFMA phases: they are
+                // L1/L2 hits and 16 registers held for the whole tile would cost a wave of occupancy
+                const float4 lsc = *reinterpret_cast<const float4*>(p.s_scale + 4 * oc4);
+                const float4 lsh = *reinterpret_cast<const float4*>(p.s_shift + 4 * oc4);
+                const float4 lmu = *reinterpret_cast<const float4*>(p.s_mean + 4 * oc4);
+                const float4 lrs = *reinterpret_cast<const float4*>(p.s_rstd + 4 * oc4);
+                constexpr int NJ = 32 / OR, HB = NJ > 4 ? 4 : NJ;     // 4 rows (16 registers of Z) at a time
 #pragma unroll
-            for (int idx = lane; idx < 32 * O4; idx += 64) {
-                const int row = idx / O4, oc = idx - row * O4;
-                if (r0 + row < p.N)
-                    *reinterpret_cast<float4*>(p.dA + (size_t)(r0 + row) * p.lda + 4 * oc) =
-                        *reinterpret_cast<const float4*>(Xs + row * XS + 4 * oc);
+                for (int j0 = 0; j0 < NJ; j0 += HB) {
+                float4 zl[HB];
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const int grow = min(r0 + orow0 + (j0 + j) * OR, nlast);
+                    zl[j] = *reinterpret_cast<const float4*>(p.sZ + (size_t)grow * p.ldsz + 4 * oc4);
+                }
+#pragma unroll
+                for (int j = 0; j < HB; ++j) {
+                    const int row = orow0 + (j0 + j) * OR;
+                    float4 g = *reinterpret_cast<const float4*>(Xs + row * XS + 4 * oc4);
+                    const float4 z = zl[j];
+                    if (!(z.x * lsc.x + lsh.x > 0.f)) g.x = 0.f;
+                    if (!(z.y * lsc.y + lsh.y > 0.f)) g.y = 0.f;
+                    if (!(z.z * lsc.z + lsh.z > 0.f)) g.z = 0.f;
+                    if (!(z.w * lsc.w + lsh.w > 0.f)) g.w = 0.f;
+                    if (r0 + row < p.N) {
+                        *reinterpret_cast<float4*>(p.dA + (size_t)(r0 + row) * p.lda + 4 * oc4) = g;
+                        ss1.x += g.x; ss1.y += g.y; ss1.z += g.z; ss1.w += g.w;
+                        ss2.x += g.x * ((z.x - lmu.x) * lrs.x); ss2.y += g.y * ((z.y - lmu.y) * lrs.y);
+                        ss2.z += g.z * ((z.z - lmu.z) * lrs.z); ss2.w += g.w * ((z.w - lmu.w) * lrs.w);
+                    }
+                }
+                }
+            } else {
+#pragma unroll
+                for (int idx = lane; idx < 32 * O4; idx += 64) {
+                    const int row = idx / O4, oc = idx - row * O4;
+                    if (r0 + row < p.N)
+                        *reinterpret_cast<float4*>(p.dA + (size_t)(r0 + row) * p.lda + 4 * oc) =
+                            *reinterpret_cast<const float4*>(Xs + row * XS + 4 * oc);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- lower-BatchNorm sums: lanes with the same column chunk, then the 4 waves (fixed order) ----
+    if constexpr (STATS) {
+        __syncthreads();
+        double* sred = reinterpret_cast<double*>(smem);           // [4 waves][2][KP]
+        float v1[4] = {ss1.x, ss1.y, ss1.z, ss1.w}, v2[4] = {ss2.x, ss2.y, ss2.z, ss2.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double d1 = (double)v1[c], d2 = (double)v2[c];
+#pragma unroll
+            for (int off = O4; off < 64; off <<= 1) {
+                d1 += __shfl_xor(d1, off, 64);
+                d2 += __shfl_xor(d2, off, 64);
+            }
+            if (lane < O4) {
+                sred[(wave * 2 + 0) * KP + 4 * oc4 + c] = d1;
+                sred[(wave * 2 + 1) * KP + 4 * oc4 + c] = d2;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * KP; idx += 256) {
+            const int which = idx / KP, col = idx - which * KP;
+            double sum = 0.0;
+            for (int w = 0; w < 4; ++w) sum += sred[(w * 2 + which) * KP + col];
+            p.s_partial[((size_t)blockIdx.x * 2 + which) * p.K + col] = sum;
         }
     }
 
@@ -1003,7 +1074,7 @@ __global__ void __launch_bounds__(256) gnm_linear_bwd_fused_kernel(const LbArgs 
     }
 }
 
-template <int KT, int HT>
+template <int KT, int HT, bool STATS>
 static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
@@ -1012,11 +1083,11 @@ static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     if (dump > lds) lds = dump;
     static bool configured = false;
     if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_linear_bwd_fused_kernel<KT, HT>),
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_linear_bwd_fused_kernel<KT, HT, STATS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         configured = true;
     }
-    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT, STATS>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
@@ -1036,7 +1107,9 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
                                     const float* rstd, const float* cA, const float* m1, const float* m2,
                                     const float* X, int ldx, const float* pro_scale, const float* pro_shift,
                                     int pro_relu, const float* W, int ldw, float* dA, int lda, float* dW, int lddw,
-                                    float* db, float* workspace, int N, int K, int H, void* stream) {
+                                    float* db, float* workspace, int N, int K, int H, const float* sZ, int ldsz,
+                                    const float* s_scale, const float* s_shift, const float* s_mean,
+                                    const float* s_rstd, double* s_partial, void* stream) {
     if (N <= 0) return GNM_ERR_UNSUPPORTED;
     if ((K != 32 && K != 64) || (H != 32 && H != 64)) return GNM_ERR_UNSUPPORTED;
     if ((ldg & 3) || (ldz & 3) || (dA && (lda & 3)) || getenv("GNM_LIN_GENERIC")) return GNM_ERR_UNSUPPORTED;
@@ -1045,7 +1118,16 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
                          reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(cA) |
                          reinterpret_cast<uintptr_t>(m1) | reinterpret_cast<uintptr_t>(m2);
     if (al & 15) return GNM_ERR_UNSUPPORTED;
+    if (sZ) {
+        if (!dA || !s_partial || (ldsz & 3)) return GNM_ERR_BAD_ARG;
+        const uintptr_t al2 = reinterpret_cast<uintptr_t>(sZ) | reinterpret_cast<uintptr_t>(s_scale) |
+                              reinterpret_cast<uintptr_t>(s_shift) | reinterpret_cast<uintptr_t>(s_mean) |
+                              reinterpret_cast<uintptr_t>(s_rstd);
+        if (al2 & 15) return GNM_ERR_UNSUPPORTED;
+    }
     LbArgs a;
+    a.sZ = sZ; a.s_scale = s_scale; a.s_shift = s_shift; a.s_mean = s_mean; a.s_rstd = s_rstd;
+    a.s_partial = s_partial; a.ldsz = ldsz;
     a.G = G; a.Z = Z; a.X = X; a.W = W; a.mean = mean; a.rstd = rstd; a.cA = cA; a.m1 = m1; a.m2 = m2;
     a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dA = dA; a.partial = workspace;
     a.ldg = ldg; a.ldz = ldz; a.ldx = ldx; a.ldw = ldw; a.lda = lda; a.N = N; a.K = K; a.H = H; a.pro_relu = pro_relu;
@@ -1053,10 +1135,10 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     const int grid = gnm_linear_bwd_grid(N);
     int rc = GNM_ERR_UNSUPPORTED;
     const int KT = K / 32, HT = H / 32;
-    if (KT == 1 && HT == 1) rc = launch_lb<1, 1>(a, grid, s);
-    if (KT == 2 && HT == 1) rc = launch_lb<2, 1>(a, grid, s);
-    if (KT == 1 && HT == 2) rc = launch_lb<1, 2>(a, grid, s);
-    if (KT == 2 && HT == 2) rc = launch_lb<2, 2>(a, grid, s);
+    if (KT == 1 && HT == 1) rc = sZ ? launch_lb<1, 1, true>(a, grid, s) : launch_lb<1, 1, false>(a, grid, s);
+    if (KT == 2 && HT == 1) rc = sZ ? launch_lb<2, 1, true>(a, grid, s) : launch_lb<2, 1, false>(a, grid, s);
+    if (KT == 1 && HT == 2) rc = sZ ? launch_lb<1, 2, true>(a, grid, s) : launch_lb<1, 2, false>(a, grid, s);
+    if (KT == 2 && HT == 2) rc = sZ ? launch_lb<2, 2, true>(a, grid, s) : launch_lb<2, 2, false>(a, grid, s);
     if (rc != GNM_OK) return rc;
     const long long stride = (long long)H * K + H;
     const int count = H * K + H;

@@ -312,26 +312,32 @@ class GinInfoMaxFn(torch.autograd.Function):
             h_in, pooled, lins = saved[l]
             F_l = h_in.shape[1]
             incoming = dH_next                       # grad wrt this layer's output from the layer above
+            pre_stats = None                         # (G, partial, nblk) when the Linear above already did them
             for k in reversed(range(m)):
                 sv = lins[k]
                 Hk, K = sv.H, sv.K
                 last = k == m - 1
                 bn = f"batch_norms.{l}" if last else f"mlps.{l}.batch_norms.{k}"
-                G = torch.empty((N, Hk), **f32)
-                part = torch.empty((B, 2, Hk), dtype=torch.float64, device=dev)
                 dp = dph[l] if last else None
                 use_disc = last and dsc1 is not None
                 Ul = U[:, l * H:(l + 1) * H] if use_disc else None
-                check(lib.gnm_bn_relu_bwd_stats(
-                    ptr(incoming), incoming.stride(0) if incoming is not None else 0,
-                    ptr(dp), dp.stride(0) if dp is not None else 0, int(spec.g_avg),
-                    ptr(dsc1) if use_disc else None, ptr(Ul), U.stride(0) if use_disc else 0,
-                    ptr(inv_perm) if use_disc else None, ptr(s2sum) if use_disc else None,
-                    sv.z.data_ptr(), sv.z.stride(0), sv.scale.data_ptr(), sv.shift.data_ptr(), sv.mean.data_ptr(),
-                    sv.rstd.data_ptr(), 1, G.data_ptr(), G.stride(0), batch.node_off.data_ptr(), B, Hk,
-                    part.data_ptr(), st), "gnm_bn_relu_bwd_stats")
+                if pre_stats is not None:
+                    G, part, nblk = pre_stats
+                    pre_stats = None
+                else:
+                  G = torch.empty((N, Hk), **f32)
+                  part = torch.empty((B, 2, Hk), dtype=torch.float64, device=dev)
+                  nblk = B
+                  check(lib.gnm_bn_relu_bwd_stats(
+                      ptr(incoming), incoming.stride(0) if incoming is not None else 0,
+                      ptr(dp), dp.stride(0) if dp is not None else 0, int(spec.g_avg),
+                      ptr(dsc1) if use_disc else None, ptr(Ul), U.stride(0) if use_disc else 0,
+                      ptr(inv_perm) if use_disc else None, ptr(s2sum) if use_disc else None,
+                      sv.z.data_ptr(), sv.z.stride(0), sv.scale.data_ptr(), sv.shift.data_ptr(), sv.mean.data_ptr(),
+                      sv.rstd.data_ptr(), 1, G.data_ptr(), G.stride(0), batch.node_off.data_ptr(), B, Hk,
+                      part.data_ptr(), st), "gnm_bn_relu_bwd_stats")
                 dgamma, dbeta, cA, m1, m2 = (torch.empty(Hk, **f32) for _ in range(5))
-                check(lib.gnm_bn_bwd_finalize(part.data_ptr(), B, Hk, N, P[bn + ".weight"].data_ptr(),
+                check(lib.gnm_bn_bwd_finalize(part.data_ptr(), nblk, Hk, N, P[bn + ".weight"].data_ptr(),
                                               sv.rstd.data_ptr(), int(ctx.training), dgamma.data_ptr(),
                                               dbeta.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), st),
                       "gnm_bn_bwd_finalize")
@@ -346,13 +352,26 @@ class GinInfoMaxFn(torch.autograd.Function):
                 dA = torch.empty((N, K), **f32) if need_dA else None
                 # one fused pass (BatchNorm-backward apply + dX + dW + db) when the shape is eligible
                 ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, Hk, K)), **f32)
+                # if a BatchNorm+ReLU feeds this Linear (k > 0), let the same pass mask dX with that ReLU and
+                # reduce that BatchNorm's backward sums (replaces its gnm_bn_relu_bwd_stats launch)
+                lo = lins[k - 1] if k > 0 else None
+                lo_part = None
+                if lo is not None and need_dA:
+                    lo_part = torch.empty((lib.gnm_linear_bwd_grid(N), 2, K), dtype=torch.float64, device=dev)
                 with _timed("linbwd_K%d_H%d" % (K, Hk), N=N, K=K, H=Hk):
                     rc = lib.gnm_linear_bwd_fused(
                         G.data_ptr(), G.stride(0), sv.z.data_ptr(), sv.z.stride(0), sv.mean.data_ptr(),
                         sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), sv.x_in.data_ptr(),
                         sv.x_in.stride(0), ptr(sv.pro[0]) if sv.pro else None, ptr(sv.pro[1]) if sv.pro else None,
                         1 if sv.pro else 0, W.data_ptr(), W.stride(0), ptr(dA), dA.stride(0) if need_dA else 0,
-                        dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), N, K, Hk, st)
+                        dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), N, K, Hk,
+                        lo.z.data_ptr() if lo_part is not None else None, lo.z.stride(0) if lo_part is not None else 0,
+                        lo.scale.data_ptr() if lo_part is not None else None,
+                        lo.shift.data_ptr() if lo_part is not None else None,
+                        lo.mean.data_ptr() if lo_part is not None else None,
+                        lo.rstd.data_ptr() if lo_part is not None else None, ptr(lo_part), st)
+                if rc == 0 and lo_part is not None:
+                    pre_stats = (dA, lo_part, lo_part.shape[0])
                 if rc == -2:        # GNM_ERR_UNSUPPORTED: generic three-kernel path
                     check(lib.gnm_bn_bwd_apply(G.data_ptr(), G.stride(0), sv.z.data_ptr(), sv.z.stride(0),
                                                sv.mean.data_ptr(), sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(),

@@ -105,7 +105,12 @@ int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int ldz, const
                          const float* cA, const float* m1, const float* m2, const float* X, int ldx,
                          const float* pro_scale, const float* pro_shift, int pro_relu, const float* W, int ldw,
                          float* dA, int lda, float* dW, int lddw, float* db, float* workspace, int N, int K, int H,
-                         void* stream);
+                         const float* sZ, int ldsz, const float* s_scale, const float* s_shift, const float* s_mean,
+                         const float* s_rstd, double* s_partial, void* stream);
+/* sZ (optional): dA is the gradient arriving at relu(bn_lo(sZ)), the BatchNorm+ReLU feeding this Linear
+ * (mlp.py:48).  Then dA is written already multiplied by that ReLU mask and s_partial receives
+ * [gnm_linear_bwd_grid(N)][2][K] doubles (sum g, sum g*xhat) for gnm_bn_bwd_finalize -- i.e. the call also
+ * replaces gnm_bn_relu_bwd_stats for the lower BatchNorm. */
 
 /* ---- BatchNorm1d + ReLU + readout (mlp.py:38,48; graphcnn.py:51,163-166,187-190,228-229) */
 int gnm_bn_finalize(const double* stats_partial, int nblk, int H, long long nrows, const float* gamma,

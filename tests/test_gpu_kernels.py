@@ -200,7 +200,8 @@ def test_linear_backward_fused(N, K, H, pro, want_dx):
                                    m1d.data_ptr(), m2d.data_ptr(), Xd.data_ptr(), K, scd.data_ptr() if pro else None,
                                    shd.data_ptr() if pro else None, 1 if pro else 0, Wd.data_ptr(), K,
                                    dA.data_ptr() if want_dx else None, K, dW.data_ptr(), K, db.data_ptr(),
-                                   ws.data_ptr(), N, K, H, _stream()), "linear_bwd_fused")
+                                   ws.data_ptr(), N, K, H, None, 0, None, None, None, None, None, _stream()),
+          "linear_bwd_fused")
     f64 = np.float64
     xhat = (Z.astype(f64) - mean) * rstd
     dZ = cA.astype(f64) * (G.astype(f64) - m1 - xhat * m2)
@@ -213,7 +214,34 @@ def test_linear_backward_fused(N, K, H, pro, want_dx):
     # ineligible shapes are refused, not mis-computed
     assert lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Zd.data_ptr(), H, md.data_ptr(), rd.data_ptr(), cd.data_ptr(),
                                     m1d.data_ptr(), m2d.data_ptr(), Xd.data_ptr(), K, None, None, 0, Wd.data_ptr(), K,
-                                    None, K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, 7, H, _stream()) == -2
+                                    None, K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, 7, H, None, 0, None,
+                                    None, None, None, None, _stream()) == -2
+    if want_dx:
+        # variant that also applies the ReLU mask of the BatchNorm+ReLU feeding this Linear to dX and
+        # reduces that BatchNorm's backward sums (what gnm_bn_relu_bwd_stats would do)
+        Zlo = (rng.standard_normal((N, K)) + 0.2).astype(np.float32)
+        lsc, lsh = rng.uniform(0.5, 1.5, K).astype(np.float32), (rng.standard_normal(K) * 0.3).astype(np.float32)
+        lmu, lrs = Zlo.mean(0).astype(np.float32), (1 / np.sqrt(Zlo.var(0) + 1e-5)).astype(np.float32)
+        Zld, lscd, lshd, lmud, lrsd = map(t, (Zlo, lsc, lsh, lmu, lrs))
+        grid = lib.gnm_linear_bwd_grid(N)
+        part = torch.full((grid, 2, K), float("nan"), dtype=torch.float64, device=DEV)
+        dA2 = torch.full((N, K), float("nan"), device=DEV)
+        check(lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Zd.data_ptr(), H, md.data_ptr(), rd.data_ptr(), cd.data_ptr(),
+                                       m1d.data_ptr(), m2d.data_ptr(), Xd.data_ptr(), K,
+                                       scd.data_ptr() if pro else None, shd.data_ptr() if pro else None,
+                                       1 if pro else 0, Wd.data_ptr(), K, dA2.data_ptr(), K, dW.data_ptr(), K,
+                                       db.data_ptr(), ws.data_ptr(), N, K, H, Zld.data_ptr(), K, lscd.data_ptr(),
+                                       lshd.data_ptr(), lmud.data_ptr(), lrsd.data_ptr(), part.data_ptr(), _stream()),
+              "linear_bwd_fused + stats")
+        mask = (Zlo * lsc + lsh) > 0                           # fp32, as the kernel evaluates it
+        Gref = (dZ @ W.astype(f64)) * mask
+        xh = (Zlo.astype(f64) - lmu) * lrs
+        assert_close(dA2.cpu().numpy(), Gref, rtol=TOL, what="masked dX")
+        st = part.sum(0).cpu().numpy()
+        fl = 1e-2 * np.abs(Gref).sum(0).max()
+        assert_close(st[0], Gref.sum(0), rtol=TOL, what="sum g", floor=fl)
+        assert_close(st[1], (Gref * xh).sum(0), rtol=TOL, what="sum g*xhat", floor=fl)
+        assert_close(dW.cpu().numpy(), dZ.T @ Xe, rtol=TOL, what="dW (stats variant)")
 
 
 @pytest.mark.parametrize("sizes,H", [([40, 40, 40], 64), ([13, 50, 7], 32), ([300, 300], 128), ([1], 64)])
