@@ -92,6 +92,14 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured hipGraph (auto: when --gpus > 1, where the host launch "
                          "cost would otherwise bound the step; the N=1 run stays eager so per-kernel HIP events exist)")
+    ap.add_argument("--neighbor-pooling", default="sum", choices=["sum", "average"])
+    ap.add_argument("--graph-pooling", default="sum", choices=["sum", "average"])
+    ap.add_argument("--keep-pct", type=float, default=30.0,
+                    help="dense-FC graphs: percent of the correlation matrix kept as edges (30 = the reference's "
+                         "default --sparsity 30 -> 47,600 directed edges; 100 = complete graph, 159,600)")
+    ap.add_argument("--no-learn-eps", action="store_true")
+    ap.add_argument("--no-direct-grads", action="store_true",
+                    help="let autograd accumulate parameter gradients instead of writing them into the flat buffer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true",
@@ -124,12 +132,13 @@ def main():
     if sparse:
         pool = synth.make_pool("knn", pool_n, first=rank * pool_n, n=n, f0=f0)
     else:
-        pool = synth.make_pool("dense_fc", pool_n, first=rank * pool_n, n=n, f0=f0)
+        pool = synth.make_pool("dense_fc", pool_n, first=rank * pool_n, n=n, f0=f0, keep_pct=args.keep_pct)
     torch.manual_seed(0)
-    model = GIN_InfoMaxReg(L, 2, f0, H, C, 0.5, True, "sum", "sum", dev).to(dev)
+    model = GIN_InfoMaxReg(L, 2, f0, H, C, 0.5, not args.no_learn_eps, args.graph_pooling, args.neighbor_pooling,
+                           dev).to(dev)
     state_cpu = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
     model.train()
-    dp = DataParallelGIN(model)
+    dp = DataParallelGIN(model, direct_grads=not args.no_direct_grads)
     dp.broadcast_parameters()
     arena = model.arena()
     gids_all = np.array([arena.add(g) for g in pool], dtype=np.int64)
@@ -209,10 +218,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[%d]: %d x %d %s graphs/step (%d directed edges each), "
-                                   "F0=7, hidden %d, %d GIN layers, 2-layer MLP, sum/sum, learn_eps, "
+                                   "F0=7, hidden %d, %d GIN layers, 2-layer MLP, %s, "
                                    "full forward (classifier + Infomax discriminator) + CE+0.05*BCE + backward%s"
                                    % (3 if sparse else (1 if world == 1 else 2), world, B,
                                       "1000-node kNN(k=20)" if sparse else "dense-FC 400-node", E, H, L,
+                                      "neighbor=%s/graph=%s%s" % (args.neighbor_pooling, args.graph_pooling,
+                                                                  "" if args.no_learn_eps else ", learn_eps"),
                                       ", flat-gradient RCCL all-reduce" if world > 1 else ""),
                        "graphs_per_gpu": B, "global_batch": B * world, "nodes_per_graph": n, "edges_per_graph": E,
                        "pool_graphs_per_gpu": pool_n, "parallelism": "dp%d" % world},
@@ -251,7 +262,9 @@ def main():
                             "hbm_GBs": (meta["N"] * H * 4 * 2) / (ms * 1e-3) / 1e9}
         out["roofline"] = roof
         out["roofline_mlp"] = roof_mlp
-        if world == 1 and not args.no_cpu_baseline and not sparse:
+        default_cfg = (args.neighbor_pooling, args.graph_pooling, args.keep_pct, args.no_learn_eps) == \
+            ("sum", "sum", 30.0, False)
+        if world == 1 and not args.no_cpu_baseline and not sparse and default_cfg:
             out["cpu_baseline"] = cpu_baseline(pool[:32], state_cpu)
         else:
             out["cpu_baseline"] = None

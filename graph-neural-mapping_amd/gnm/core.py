@@ -91,6 +91,11 @@ class GinSpec:
         self.learn_eps = bool(learn_eps)
         self.g_avg = graph_pooling_type == "average"
         self.n_avg = neighbor_pooling_type == "average"
+        # Optional gradient sink {parameter name: tensor}: when set (gnm.parallel.DataParallelGIN
+        # points it at views of its flat gradient buffer) the backward kernels write every parameter
+        # gradient straight into these tensors (OVERWRITING them) and autograd gets None, instead of
+        # fresh tensors that AccumulateGrad then adds into .grad with ~50 tiny kernels per step.
+        self.grad_sink = None
 
 
 def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None):
@@ -265,6 +270,18 @@ class GinInfoMaxFn(torch.autograd.Function):
         st = _stream()
         grads = {}
         need_dx = ctx.needs_input_grad[8]
+        sink = spec.grad_sink
+
+        def out_like(name, ref):
+            """tensor the kernel should write gradient `name` into"""
+            return sink[name] if sink is not None else torch.empty_like(ref)
+
+        def put(name, value):
+            """record a gradient computed by a torch op"""
+            if sink is not None:
+                sink[name].copy_(value.reshape(sink[name].shape))
+            else:
+                grads[name] = value
 
         # ---- discriminator (discriminator.py:28-36) --------------------------------
         dsc1 = U = inv_perm = s2sum = None
@@ -278,8 +295,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                                          ctx.perm_rows.data_ptr(), batch.node_off.data_ptr(), N, B, dU.data_ptr(),
                                          dU.stride(0), s2sum.data_ptr(), st), "gnm_disc_score_bwd")
             Wd = P["disc.f_k.weight"][0]
-            grads["disc.f_k.weight"] = (dU.t() @ c).unsqueeze(0)
-            grads["disc.f_k.bias"] = dD.sum().reshape(1)
+            put("disc.f_k.weight", (dU.t() @ c).unsqueeze(0))
+            put("disc.f_k.bias", dD.sum().reshape(1))
             dg_f = (dU @ Wd) * c * (1 - c)                                    # sigmoid backward
             dsc1 = dD                                                         # first N entries = d sc_1
             inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
@@ -295,8 +312,8 @@ class GinInfoMaxFn(torch.autograd.Function):
             dWp = torch.bmm(dlg.transpose(1, 2), G3)                                     # [L,C,H]
             dbp = dlg.sum(1)                                                             # [L,C]
             for l in range(L):
-                grads[f"linears_prediction.{l}.weight"] = dWp[l]
-                grads[f"linears_prediction.{l}.bias"] = dbp[l]
+                put(f"linears_prediction.{l}.weight", dWp[l])
+                put(f"linears_prediction.{l}.bias", dbp[l])
             if dg_f is not None:
                 dph_all = torch.baddbmm(dg_f.view(B, L, H).transpose(0, 1), dlg, ctx.Wp)   # [L,B,H] contiguous
             else:
@@ -305,7 +322,9 @@ class GinInfoMaxFn(torch.autograd.Function):
             dph_all = dg_f.view(B, L, H).transpose(0, 1).contiguous()
         dph = [dph_all[l] if dph_all is not None else None for l in range(L)]
 
-        deps = torch.zeros(L, **f32) if spec.learn_eps else None
+        deps = None
+        if spec.learn_eps:
+            deps = sink["eps"] if sink is not None else torch.zeros(L, **f32)
         dH_next = None
         dX = None
         for l in reversed(range(L)):
@@ -336,16 +355,18 @@ class GinInfoMaxFn(torch.autograd.Function):
                       sv.z.data_ptr(), sv.z.stride(0), sv.scale.data_ptr(), sv.shift.data_ptr(), sv.mean.data_ptr(),
                       sv.rstd.data_ptr(), 1, G.data_ptr(), G.stride(0), batch.node_off.data_ptr(), B, Hk,
                       part.data_ptr(), st), "gnm_bn_relu_bwd_stats")
-                dgamma, dbeta, cA, m1, m2 = (torch.empty(Hk, **f32) for _ in range(5))
+                dgamma, dbeta = out_like(bn + ".weight", sv.scale), out_like(bn + ".bias", sv.scale)
+                cA, m1, m2 = (torch.empty(Hk, **f32) for _ in range(3))
                 check(lib.gnm_bn_bwd_finalize(part.data_ptr(), nblk, Hk, N, P[bn + ".weight"].data_ptr(),
                                               sv.rstd.data_ptr(), int(ctx.training), dgamma.data_ptr(),
                                               dbeta.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), st),
                       "gnm_bn_bwd_finalize")
-                grads[bn + ".weight"], grads[bn + ".bias"] = dgamma, dbeta
+                if sink is None:
+                    grads[bn + ".weight"], grads[bn + ".bias"] = dgamma, dbeta
                 wname = f"mlps.{l}.linear" if m == 1 else f"mlps.{l}.linears.{k}"
                 W = P[wname + ".weight"]
-                dW = torch.empty_like(W)
-                db = torch.empty(Hk, **f32)
+                dW = out_like(wname + ".weight", W)
+                db = out_like(wname + ".bias", sv.scale)
                 # dX of this Linear: always for inner Linears; for the first one only when the
                 # aggregation backward below has a consumer (a lower layer, dX, or d eps[l])
                 need_dA = k > 0 or l > 0 or need_dx or spec.learn_eps
@@ -389,7 +410,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                         _linear_wide(dZ, W, 1, None, dA, N, Hk, K, None, None)      # dX = dZ W
                 else:
                     check(rc, "gnm_linear_bwd_fused")
-                grads[wname + ".weight"], grads[wname + ".bias"] = dW, db
+                if sink is None:
+                    grads[wname + ".weight"], grads[wname + ".bias"] = dW, db
                 incoming = dA
             # aggregation backward: d h_{l-1} = A^T (dpooled [/deg]) + (1+eps) dpooled ; d eps[l]
             if incoming is not None:
@@ -409,7 +431,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                     dH_next = dh
                 else:
                     dX = dh
-        if spec.learn_eps:
+        if spec.learn_eps and sink is None:
             grads["eps"] = deps
         out = [None] * 8 + [dX if need_dx else None]
         for i, name in enumerate(ctx.names):

@@ -46,12 +46,25 @@ class DataParallelGIN:
     """Wraps a GIN_InfoMaxReg replica.  broadcast_parameters() once, then per step:
     zero_grad(); loss(forward(local shard)).backward(); allreduce_gradients()."""
 
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, direct_grads=True):
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.fp = FlatParams(model)
+        # GIN_InfoMaxReg: let the backward kernels write gradients straight into the flat buffer
+        # (overwrite semantics: every step produces every gradient, so no zeroing and no
+        # AccumulateGrad adds are needed; see GinSpec.grad_sink)
+        self.direct = False
+        spec = getattr(model, "_spec", None)
+        if direct_grads and spec is not None and getattr(model, "neighbor_pooling_type", "max") != "max":
+            sink, off = {}, 0
+            names = [n for n, _ in model.named_parameters()]
+            for n, p in zip(names, self.fp.params):
+                sink[n] = self.fp.flat_grad[off:off + p.numel()].view_as(p.data)
+                off += p.numel()
+            spec.grad_sink = sink
+            self.direct = True
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
@@ -68,6 +81,8 @@ class DataParallelGIN:
         return global_items[self.rank * per:(self.rank + 1) * per]
 
     def zero_grad(self):
+        if self.direct:
+            return          # every gradient is overwritten by the next backward
         self.fp.zero_grad()
 
     def allreduce_gradients(self, async_op=False):
