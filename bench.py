@@ -113,11 +113,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py ..."
                              % (args.gpus, args.gpus))
+    # test hook (1-GPU box): GNM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, which exercises the
+    # whole N > 1 code path except RCCL itself
+    share = os.environ.get("GNM_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from gnm import core, synth
     from gnm.parallel import DataParallelGIN, seed_rank_rng

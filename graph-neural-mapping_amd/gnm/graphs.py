@@ -39,7 +39,8 @@ class CapturedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads of the process (e.g. RCCL's watchdog) keep issuing HIP calls
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._step()
         torch.cuda.synchronize()
 
