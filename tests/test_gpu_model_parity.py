@@ -397,3 +397,59 @@ def test_gradient_sink_matches_autograd_accumulation(case):
         for p in model.parameters():
             assert p.grad is not None
     assert torch.equal(res[0], res[1])
+
+
+def test_one_hot_input_features_default_of_the_reference():
+    """main.py's default --input_feature one_hot gives node_features = identity (F0 = n, util.py:115):
+    layer 0 aggregates 400-wide rows (7 feature slices of 64) and its first Linear has K = 400.
+    Whole training step against the fp64 oracle; saliency too (dX through the K = 400 Linear)."""
+    from gnm import synth
+    from models.graphcnn import GIN_InfoMaxReg
+    from oracle import gin_oracle as O
+    n, L, m, H, C, B = 400, 2, 2, 64, 2, 2
+    graphs = []
+    for g in range(B):
+        gr = synth.dense_fc_graph(g, n=n, f0=1)
+        gr.node_features = torch.eye(n)                     # one-hot ROI identity
+        graphs.append(gr)
+    dev = torch.device(DEV)
+    torch.manual_seed(9)
+    model = GIN_InfoMaxReg(L, m, n, H, C, 0.0, True, "sum", "sum", dev).to(dev).train()
+    state = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    np.random.seed(2)
+    perm = np.random.permutation(B)
+    np.random.seed(2)
+    c_logit, d_logit = model(graphs)
+    N = B * n
+    labels = torch.tensor([g.label for g in graphs], device=dev)
+    d_labels = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev)
+    loss = torch.nn.CrossEntropyLoss()(c_logit, labels) + 0.05 * torch.nn.BCEWithLogitsLoss()(d_logit, d_labels)
+    loss.backward()
+    ob = [O.OGraph(n, g.edge_mat.numpy(), g.node_features.numpy(), g.label) for g in graphs]
+    om = O.OracleGIN(state, L, m, True, "sum", "sum", dtype=np.float64)
+    truth = om.train_step_grads(ob, perm)
+    assert_close(c_logit.detach().cpu().numpy(), truth["c_logit"], rtol=2 * RTOL, what="c_logit")
+    assert_close(d_logit.detach().cpu().numpy(), truth["d_logit"], rtol=2 * RTOL, what="d_logit")
+    floor = 2e-2 * max(float(np.abs(v).max()) for v in truth["grads"].values())
+    for name, p in model.named_parameters():
+        assert_close(p.grad.cpu().numpy(), truth["grads"][name].reshape(p.shape), rtol=TRUE_SHAPE_GRAD_RTOL,
+                     what=name, floor=floor)
+    sal = model.compute_saliency([graphs[0]], 1)
+    om2 = O.OracleGIN(state, L, m, True, "sum", "sum", dtype=np.float64)
+    for k, v in model.state_dict().items():                  # running stats moved during the train step
+        om2.p[k] = v.detach().cpu().numpy().astype(np.float64) if v.dtype.is_floating_point else v.cpu().numpy()
+    ref = om2.compute_saliency(ob[0], 1)
+    assert sal.shape == (n, n)
+    assert_close(sal.cpu().numpy(), ref, rtol=TRUE_SHAPE_GRAD_RTOL, what="saliency", floor=1e-2 * np.abs(ref).max())
+
+
+def test_ragged_batch_is_rejected_like_the_reference():
+    """discriminator.py:24 expands each graph summary N//B times: graphs of different sizes
+    cannot go through forward() (the reference fails with a shape error in nn.Bilinear)."""
+    from gnm import synth
+    from models.graphcnn import GIN_InfoMaxReg
+    dev = torch.device(DEV)
+    graphs = [synth.dense_fc_graph(0, n=40, t=64), synth.dense_fc_graph(1, n=48, t=64)]
+    model = GIN_InfoMaxReg(2, 2, 7, 32, 2, 0.0, True, "sum", "sum", dev).to(dev)
+    with pytest.raises(RuntimeError):
+        model(graphs)
