@@ -619,12 +619,15 @@ __global__ void __launch_bounds__(256) gnm_wgrad_fast_kernel(const WgArgs p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float dbacc[WI];
     int hcol[WI], kcol[WJ];
+    bool kok[WJ];                 // columns past the window / K are clamped on load and zeroed by select
     float sc[WJ], sh[WJ];
 #pragma unroll
     for (int a = 0; a < WI; ++a) { dbacc[a] = 0.f; hcol[a] = 32 * (qi * WI + a) + i; }
 #pragma unroll
     for (int b = 0; b < WJ; ++b) {
-        kcol[b] = p.k0 + 32 * (qj * WJ + b) + i;
+        const int kl = 32 * (qj * WJ + b) + i;
+        kok[b] = (kl < p.kw) && (p.k0 + kl < p.K);
+        kcol[b] = min(p.k0 + kl, p.K - 1);
         sc[b] = p.pro_scale ? p.pro_scale[kcol[b]] : 1.f;
         sh[b] = p.pro_scale ? p.pro_shift[kcol[b]] : 0.f;
     }
@@ -653,7 +656,7 @@ __global__ void __launch_bounds__(256) gnm_wgrad_fast_kernel(const WgArgs p) {
                     x = x * sc[b] + sh[b];
                     if (p.pro_relu) x = fmaxf(x, 0.f);
                 }
-                bv[u][b] = rok ? x : 0.f;
+                bv[u][b] = (rok && kok[b]) ? x : 0.f;
             }
 #pragma unroll
             for (int a = 0; a < WI; ++a) {
@@ -1169,7 +1172,7 @@ extern "C" int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ld
         const int WI = HT < 2 ? HT : 2, WJ = KT < 2 ? KT : 2;
         const int QI = (HT + WI - 1) / WI, QJ = (KT + WJ - 1) / WJ;
         int rc = GNM_ERR_UNSUPPORTED;
-        const bool fast = (H % 32) == 0 && (kw % 32) == 0 && N > 0 && !getenv("GNM_LIN_GENERIC");
+        const bool fast = (H % 32) == 0 && N > 0 && !getenv("GNM_LIN_GENERIC");
 #define GNM_WG_CASE(WI_, WJ_, QI_, QJ_)                                                       \
     if (WI == WI_ && WJ == WJ_ && QI == QI_ && QJ == QJ_)                                     \
         rc = fast ? launch_wgrad_fast<WI_, WJ_, QI_, QJ_>(a, grid, s) : launch_wgrad<WI_, WJ_, QI_, QJ_>(a, grid, s);
