@@ -31,6 +31,7 @@
 // In backward it also produces d eps[layer] = sum dpooled * h (fp64 partials).
 #include "gnm_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 struct AggArgs {
     const int32_t* rowptr;     // gather structure arena (forward CSR, or transposed for backward)
@@ -49,6 +50,13 @@ struct AggArgs {
     int F;                     // valid feature width
     int nslices;
     int average, self_loop, backward;
+    // optional fusion (agg16, backward, one slice): y is the gradient arriving at relu(bn(sZ)) of the layer
+    // below -- add the readout / discriminator terms, apply that ReLU mask, write G and reduce the
+    // BatchNorm-backward sums (replaces gnm_bn_relu_bwd_stats for that BatchNorm)
+    const float* sZ; const float* s_scale; const float* s_shift; const float* s_mean; const float* s_rstd;
+    const float* s_dpool; const float* s_dsc1; const float* s_U; const int32_t* s_inv_perm; const float* s_s2sum;
+    double* s_partial;         // [B][2][64]
+    int ldsz, ld_dpool, ld_U, s_avg, n_batch;
     int ids_in_lds;            // narrow slices: the graph's column ids are staged in LDS (max_nnz given)
     int debug;                 // tuning only (GNM_AGG16_DEBUG): 1 no id loads, 2 no epilogue/store, 4 no combine
 };
@@ -397,6 +405,7 @@ __device__ __forceinline__ float4 shfl_xor4(const float4 v, int m) {
                        __shfl_xor(v.w, m, 64));
 }
 
+template <bool STATS>
 __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     constexpr int LPR = 16;
     constexpr int FS = 64;
@@ -509,6 +518,23 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
     const bool vec_out = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
     const int ngroups = p.y ? (n + 3) >> 2 : 0;
+    // fused BatchNorm-backward statistics of the layer below (STATS): per-lane column chunk `sub`
+    float4 ss1 = make_float4(0.f, 0.f, 0.f, 0.f), ss2 = ss1, s_pb = ss1, s_ub = ss1;
+    float4 lsc = ss1, lsh = ss1, lmu = ss1, lrs = ss1;
+    if constexpr (STATS) {
+        lsc = *reinterpret_cast<const float4*>(p.s_scale + 4 * sub);
+        lsh = *reinterpret_cast<const float4*>(p.s_shift + 4 * sub);
+        lmu = *reinterpret_cast<const float4*>(p.s_mean + 4 * sub);
+        lrs = *reinterpret_cast<const float4*>(p.s_rstd + 4 * sub);
+        if (p.s_dpool) {
+            s_pb = *reinterpret_cast<const float4*>(p.s_dpool + (size_t)b * p.ld_dpool + 4 * sub);
+            if (p.s_avg) {
+                const float w = 1.0f / (float)n;
+                s_pb.x *= w; s_pb.y *= w; s_pb.z *= w; s_pb.w *= w;
+            }
+        }
+        if (p.s_dsc1) s_ub = *reinterpret_cast<const float4*>(p.s_U + (size_t)b * p.ld_U + 4 * sub);
+    }
 
     // Groups of 4 consecutive rows are dealt round-robin to the waves (group g -> wave g % nwaves).
     // No LDS round trip sits on the per-row critical path: under load the LDS queue is ~1000
@@ -547,6 +573,13 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
             // is not a dependent LDS round trip behind ~256 queued reads in the epilogue
             const int v = 4 * g + q;
             const float4 self = tile[min(v, n) * LPR + sub];
+            float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
+            float dsc_v = 0.f;
+            if constexpr (STATS) {     // requested ahead of the gather, consumed in the epilogue
+                const int vc = row0 + min(v, n - 1);
+                zrow = *reinterpret_cast<const float4*>(p.sZ + (size_t)vc * p.ldsz + 4 * sub);
+                if (p.s_dsc1) dsc_v = p.s_dsc1[vc];
+            }
             // degree of row v from the rowptr lane vector (no LDS): 5 readlanes + selects
             const int b0 = __builtin_amdgcn_readlane(rpv, 8 * kk), b1 = __builtin_amdgcn_readlane(rpv, 8 * kk + 1),
                       b2 = __builtin_amdgcn_readlane(rpv, 8 * kk + 2), b3 = __builtin_amdgcn_readlane(rpv, 8 * kk + 3),
@@ -578,11 +611,15 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 while (cnt > 0) {
                     const int c64 = min(cnt, 64);
                     const int steps = (c64 + 3) >> 2;          // wave-uniform
-                    if (steps > 12) {
-                        GNM_BLOCK16()                          // 16 ds_read_b128 in flight
+                    // 16 ds_read_b128 in flight per block; the STATS variant needs the 32 registers and uses
+                    // two 8-deep blocks (measured within noise of 16-deep at 16 waves/CU)
+                    if (steps > 12 && !STATS) {
+                        GNM_BLOCK16()
+                    } else if (steps > 8) {
+                        GNM_BLOCK8(0)
+                        if (steps > 12) GNM_BLOCK8(1) else GNM_GROUP4(2)
                     } else if (steps > 4) {
                         GNM_BLOCK8(0)
-                        if (steps > 8) GNM_GROUP4(2)
                     } else {
                         GNM_GROUP4(0)
                     }
@@ -628,6 +665,24 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                     }
                     tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
                 }
+                if constexpr (STATS) {
+                    // total gradient at this layer output = aggregation backward + readout + discriminator terms
+                    tot.x += s_pb.x + dsc_v * s_ub.x; tot.y += s_pb.y + dsc_v * s_ub.y;
+                    tot.z += s_pb.z + dsc_v * s_ub.z; tot.w += s_pb.w + dsc_v * s_ub.w;
+                    if (p.s_dsc1 && row0 + v < p.n_batch) {     // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
+                        const int gq = p.s_inv_perm[row0 + v];
+                        const float s2 = p.s_s2sum[gq];
+                        const float4 uq = *reinterpret_cast<const float4*>(p.s_U + (size_t)gq * p.ld_U + 4 * sub);
+                        tot.x += s2 * uq.x; tot.y += s2 * uq.y; tot.z += s2 * uq.z; tot.w += s2 * uq.w;
+                    }
+                    if (!(zrow.x * lsc.x + lsh.x > 0.f)) tot.x = 0.f;
+                    if (!(zrow.y * lsc.y + lsh.y > 0.f)) tot.y = 0.f;
+                    if (!(zrow.z * lsc.z + lsh.z > 0.f)) tot.z = 0.f;
+                    if (!(zrow.w * lsc.w + lsh.w > 0.f)) tot.w = 0.f;
+                    ss1.x += tot.x; ss1.y += tot.y; ss1.z += tot.z; ss1.w += tot.w;
+                    ss2.x += tot.x * ((zrow.x - lmu.x) * lrs.x); ss2.y += tot.y * ((zrow.y - lmu.y) * lrs.y);
+                    ss2.z += tot.z * ((zrow.z - lmu.z) * lrs.z); ss2.w += tot.w * ((zrow.w - lmu.w) * lrs.w);
+                }
                 float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
                 if (vec_out && cc + 3 < p.F) {
                     *reinterpret_cast<float4*>(dst) = tot;
@@ -639,6 +694,30 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 }
             }
         }
+    }
+
+    if constexpr (STATS) {     // column sums: the 4 quarters of a wave, then the waves, in a fixed order
+        __syncthreads();
+        double* sred = reinterpret_cast<double*>(smem) + 64;      // [nwaves][2][64] (after the d-eps slots)
+        const float v1[4] = {ss1.x, ss1.y, ss1.z, ss1.w}, v2[4] = {ss2.x, ss2.y, ss2.z, ss2.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double d1 = (double)v1[c], d2 = (double)v2[c];
+            d1 += __shfl_xor(d1, 16, 64); d2 += __shfl_xor(d2, 16, 64);
+            d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
+            if (lane < 16) {
+                sred[(wave * 2 + 0) * 64 + 4 * sub + c] = d1;
+                sred[(wave * 2 + 1) * 64 + 4 * sub + c] = d2;
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, col = tid & 63;
+            double sum = 0.0;
+            for (int w = 0; w < nwaves; ++w) sum += sred[(w * 2 + which) * 64 + col];
+            p.s_partial[((size_t)blockIdx.x * 2 + which) * 64 + col] = sum;
+        }
+        __syncthreads();
     }
 
     if (p.deps_partial) {
@@ -659,7 +738,9 @@ static int launch_agg16(const AggArgs& a, int B, int n_max, hipStream_t stream) 
     const size_t lds = (size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 16;
     static bool configured = false;
     if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg16_kernel),
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg16_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg16_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         configured = true;
     }
@@ -670,7 +751,10 @@ static int launch_agg16(const AggArgs& a, int B, int n_max, hipStream_t stream) 
         const int t = atoi(e);
         if (t >= 64 && t <= 1024 && (t & 63) == 0) threads = t;
     }
-    hipLaunchKernelGGL(gnm_agg16_kernel, dim3(B * a.nslices), dim3(threads), lds, stream, a);
+    if (a.sZ)
+        hipLaunchKernelGGL(gnm_agg16_kernel<true>, dim3(B * a.nslices), dim3(threads), lds, stream, a);
+    else
+        hipLaunchKernelGGL(gnm_agg16_kernel<false>, dim3(B * a.nslices), dim3(threads), lds, stream, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
@@ -725,6 +809,7 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
     const int fs = gnm_agg_slice_width(F, n_max);
     if (fs == 0) return GNM_ERR_UNSUPPORTED;   // graph too large for an LDS-resident slice
     AggArgs a;
+    memset(&a, 0, sizeof(a));
     a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
     a.deg_rowptr = deg_rowptr ? deg_rowptr : rowptr;
     a.b_deg_off = b_deg_off ? b_deg_off : b_rp_off;
@@ -745,6 +830,45 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
         case 128: return launch_agg<32>(a, B, n_max, s);
     }
     return GNM_ERR_UNSUPPORTED;
+}
+
+// Aggregation backward fused with the BatchNorm-backward statistics of the layer below
+// (see AggArgs): only for the 64-wide single-slice shape; GNM_ERR_UNSUPPORTED otherwise.
+static AggArgs g_stats_none() {
+    AggArgs z;
+    memset(&z, 0, sizeof(z));
+    return z;
+}
+extern "C" int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
+                                 const int64_t* b_col_off, const int32_t* deg_rowptr, const int64_t* b_deg_off,
+                                 const int32_t* node_off, int B, int n_max, int nnz_max, const float* x, int ldx,
+                                 float* y, int ldy, int F, const float* eps, int average, int self_loop,
+                                 const float* hfwd, int ldh, double* deps_partial, const float* sZ, int ldsz,
+                                 const float* s_scale, const float* s_shift, const float* s_mean, const float* s_rstd,
+                                 const float* dpool, int ld_dpool, int graph_avg, const float* dsc1, const float* U,
+                                 int ld_U, const int32_t* inv_perm, const float* s2sum, double* s_partial,
+                                 void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (F != 64 || gnm_agg_slice_width(F, n_max) != 64 || !y || !sZ || !s_partial) return GNM_ERR_UNSUPPORTED;
+    if ((ldsz & 3) || (ldy & 3) || (dpool && (ld_dpool & 3)) || (dsc1 && (ld_U & 3))) return GNM_ERR_UNSUPPORTED;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(sZ) | reinterpret_cast<uintptr_t>(s_scale) |
+                         reinterpret_cast<uintptr_t>(s_shift) | reinterpret_cast<uintptr_t>(s_mean) |
+                         reinterpret_cast<uintptr_t>(s_rstd) | reinterpret_cast<uintptr_t>(dpool) |
+                         reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(y);
+    if (al & 15) return GNM_ERR_UNSUPPORTED;
+    if (deps_partial && !hfwd) return GNM_ERR_BAD_ARG;
+    AggArgs a = g_stats_none();
+    a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
+    a.deg_rowptr = deg_rowptr ? deg_rowptr : rowptr;
+    a.b_deg_off = b_deg_off ? b_deg_off : b_rp_off;
+    a.node_off = node_off; a.x = x; a.y = y; a.eps = eps; a.hfwd = hfwd; a.deps_partial = deps_partial;
+    a.ldx = ldx; a.ldy = ldy; a.ldh = ldh; a.F = F; a.nslices = 1;
+    a.average = average; a.self_loop = self_loop; a.backward = 1;
+    a.sZ = sZ; a.s_scale = s_scale; a.s_shift = s_shift; a.s_mean = s_mean; a.s_rstd = s_rstd;
+    a.s_dpool = dpool; a.s_dsc1 = dsc1; a.s_U = U; a.s_inv_perm = inv_perm; a.s_s2sum = s2sum;
+    a.s_partial = s_partial; a.ldsz = ldsz; a.ld_dpool = ld_dpool; a.ld_U = ld_U; a.s_avg = graph_avg;
+    a.n_batch = B;
+    return launch_agg16(a, B, n_max, reinterpret_cast<hipStream_t>(stream));
 }
 
 // Number of deps partials gnm_agg writes for (F, n_max, B): B * nslices.

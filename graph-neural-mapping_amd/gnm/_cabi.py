@@ -19,6 +19,8 @@ SIGNATURES = {
     "gnm_csr_is_symmetric": (_i, [_p, _p, _i]),
     "gnm_batch_coo_from_csr": (_ll, [_p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "gnm_agg": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p]),
+    "gnm_agg_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p, _i, _p,
+                               _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
     "gnm_agg_slice_width": (_i, [_i, _i]),
     "gnm_agg_num_partials": (_i, [_i, _i, _i]),
     "gnm_sum_partials": (_i, [_p, _i, _p, _p]),

@@ -327,11 +327,15 @@ class GinInfoMaxFn(torch.autograd.Function):
             deps = sink["eps"] if sink is not None else torch.zeros(L, **f32)
         dH_next = None
         dX = None
+        pre_outer = None
         for l in reversed(range(L)):
             h_in, pooled, lins = saved[l]
             F_l = h_in.shape[1]
             incoming = dH_next                       # grad wrt this layer's output from the layer above
-            pre_stats = None                         # (G, partial, nblk) when the Linear above already did them
+            # (G, partial, nblk) when the producer of this gradient already applied the ReLU mask and reduced
+            # the BatchNorm-backward sums: the aggregation backward of the layer above (outer BatchNorm) or
+            # the fused backward of the Linear above (inner BatchNorms)
+            pre_stats, pre_outer = pre_outer, None
             for k in reversed(range(m)):
                 sv = lins[k]
                 Hk, K = sv.H, sv.K
@@ -422,8 +426,36 @@ class GinInfoMaxFn(torch.autograd.Function):
                 if spec.learn_eps:
                     part = torch.empty(lib.gnm_agg_num_partials(F_l, batch.n_max, B), dtype=torch.float64, device=dev)
                 eps_ptr = P["eps"].data_ptr() + 4 * l if spec.learn_eps else None
-                _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True, hfwd=h_in if spec.learn_eps else None,
-                     deps_partial=part)
+                fused = False
+                if l > 0 and want_dh:
+                    # also do the layer below's outer-BatchNorm backward pass 1 in the same kernel
+                    lo = saved[l - 1][2][-1]
+                    use_disc = dsc1 is not None
+                    Ulo = U[:, (l - 1) * H:l * H] if use_disc else None
+                    dplo = dph[l - 1]
+                    spart = torch.empty((B, 2, F_l), dtype=torch.float64, device=dev)
+                    a = batch.arena
+                    with _timed("agg_bwd_F%d" % F_l, F=F_l, B=B, N=N):
+                        rc = lib.gnm_agg_bwd_stats(
+                            a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
+                            batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
+                            batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, dpooled.data_ptr(),
+                            dpooled.stride(0), dh.data_ptr(), dh.stride(0), F_l, eps_ptr, int(spec.n_avg),
+                            int(not spec.learn_eps), ptr(h_in) if spec.learn_eps else None,
+                            h_in.stride(0) if spec.learn_eps else 0, ptr(part), lo.z.data_ptr(), lo.z.stride(0),
+                            lo.scale.data_ptr(), lo.shift.data_ptr(), lo.mean.data_ptr(), lo.rstd.data_ptr(),
+                            ptr(dplo), dplo.stride(0) if dplo is not None else 0, int(spec.g_avg),
+                            ptr(dsc1) if use_disc else None, ptr(Ulo), U.stride(0) if use_disc else 0,
+                            ptr(inv_perm) if use_disc else None, ptr(s2sum) if use_disc else None, spart.data_ptr(),
+                            st)
+                    if rc == 0:
+                        fused = True
+                        pre_outer = (dh, spart, B)
+                    elif rc != -2:
+                        check(rc, "gnm_agg_bwd_stats")
+                if not fused:
+                    _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True,
+                         hfwd=h_in if spec.learn_eps else None, deps_partial=part)
                 if spec.learn_eps:
                     check(lib.gnm_sum_partials(part.data_ptr(), part.numel(), deps.data_ptr() + 4 * l, st),
                           "gnm_sum_partials")

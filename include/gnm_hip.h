@@ -72,6 +72,18 @@ int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
             const int32_t* deg_rowptr, const int64_t* b_deg_off, const int32_t* node_off, int B, int n_max,
             int nnz_max, const float* x, int ldx, float* y, int ldy, int F, const float* eps, int average, int self_loop,
             int backward, const float* hfwd, int ldh, double* deps_partial, void* stream);
+/* gnm_agg(backward = 1) for the layer-output gradient, fused with what gnm_bn_relu_bwd_stats would then do
+ * for the BatchNorm+ReLU that produced that layer output (graphcnn.py:163-166 of the layer below): y becomes
+ * G = (A^T x [+ self terms] + w_b*dpool[b] + dsc1[v]*U[b] + quirk rows) * relu-mask(sZ), and s_partial receives
+ * [B][2][64] doubles (sum G, sum G*xhat) for gnm_bn_bwd_finalize.  Only for F = 64 with the whole [n, 64] tile
+ * in LDS; GNM_ERR_UNSUPPORTED otherwise (nothing is launched).  dpool / dsc1 (with U, inv_perm, s2sum) may be null. */
+int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
+                      const int32_t* deg_rowptr, const int64_t* b_deg_off, const int32_t* node_off, int B, int n_max,
+                      int nnz_max, const float* x, int ldx, float* y, int ldy, int F, const float* eps, int average,
+                      int self_loop, const float* hfwd, int ldh, double* deps_partial, const float* sZ, int ldsz,
+                      const float* s_scale, const float* s_shift, const float* s_mean, const float* s_rstd,
+                      const float* dpool, int ld_dpool, int graph_avg, const float* dsc1, const float* U, int ld_U,
+                      const int32_t* inv_perm, const float* s2sum, double* s_partial, void* stream);
 int gnm_agg_slice_width(int F, int n_max);          /* feature-slice width the kernel will use (0: unsupported) */
 int gnm_agg_num_partials(int F, int n_max, int B);  /* doubles written to deps_partial */
 int gnm_sum_partials(const double* partial, int count, float* out, void* stream);

@@ -127,6 +127,78 @@ def test_agg_forward_backward(sizes, density, F, symmetric, average, learn_eps):
         assert abs(out.item() - want) <= 1e-6 * scale        # fp64 accumulation: far below fp32 noise
 
 
+@pytest.mark.parametrize("sizes,density", [([40, 40, 40], 0.3), ([400, 400], 0.3), ([64] * 9, 0.5)])
+@pytest.mark.parametrize("average,learn_eps,graph_avg,disc", [(0, 1, 0, True), (1, 1, 1, True), (0, 0, 0, False),
+                                                              (1, 0, 1, True)])
+def test_agg_backward_fused_with_bn_stats(sizes, density, average, learn_eps, graph_avg, disc):
+    """gnm_agg_bwd_stats == gnm_agg(backward) followed by gnm_bn_relu_bwd_stats (readout, discriminator and
+    quirk-row terms, ReLU mask, per-graph BatchNorm-backward sums), to fp32 rounding."""
+    from gnm import core
+    from gnm._cabi import check, lib
+    from gnm.arena import GraphArena
+    rng = np.random.default_rng(len(sizes) * 1000 + average * 10 + learn_eps)
+    graphs = random_graphs(rng, sizes, density, True)
+    ar = GraphArena(DEV)
+    batch = ar.batch(graphs)
+    N, B, F = batch.N, batch.B, 64
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    dp = t(rng.standard_normal((N, F)).astype(np.float32))
+    hf = t(rng.standard_normal((N, F)).astype(np.float32))
+    Z = t((rng.standard_normal((N, F)) + 0.3).astype(np.float32))
+    sc, sh = t(rng.uniform(0.5, 1.5, F).astype(np.float32)), t((rng.standard_normal(F) * 0.3).astype(np.float32))
+    mu, rs = t(rng.standard_normal(F).astype(np.float32) * 0.1), t(rng.uniform(0.5, 1.5, F).astype(np.float32))
+    dpool = t(rng.standard_normal((B, F)).astype(np.float32))
+    dsc1 = t(rng.standard_normal(N).astype(np.float32)) if disc else None
+    U = t(rng.standard_normal((B, 3 * F)).astype(np.float32))          # a [B, L*H] buffer; layer slice 1
+    Ul = U[:, F:2 * F]
+    perm = rng.permutation(B)
+    inv = np.empty(B, dtype=np.int32); inv[perm] = np.arange(B, dtype=np.int32)
+    invd, s2 = t(inv), t(rng.standard_normal(B).astype(np.float32))
+    eps = torch.tensor([0.25], device=DEV)
+    spec = core.GinSpec(1, 1, bool(learn_eps), "average" if graph_avg else "sum", "average" if average else "sum")
+    epsp = eps.data_ptr() if learn_eps else None
+    # reference: two kernels
+    dh = torch.empty((N, F), device=DEV)
+    part_e = torch.empty(lib.gnm_agg_num_partials(F, batch.n_max, B), dtype=torch.float64, device=DEV)
+    core._agg(batch, dp, dh, F, epsp, spec, backward=True, hfwd=hf if learn_eps else None,
+              deps_partial=part_e if learn_eps else None)
+    G_ref = torch.empty((N, F), device=DEV)
+    p_ref = torch.empty((B, 2, F), dtype=torch.float64, device=DEV)
+    check(lib.gnm_bn_relu_bwd_stats(dh.data_ptr(), F, dpool.data_ptr(), F, graph_avg,
+                                    dsc1.data_ptr() if disc else None, Ul.data_ptr() if disc else None,
+                                    U.stride(0) if disc else 0, invd.data_ptr() if disc else None,
+                                    s2.data_ptr() if disc else None, Z.data_ptr(), F, sc.data_ptr(), sh.data_ptr(),
+                                    mu.data_ptr(), rs.data_ptr(), 1, G_ref.data_ptr(), F, batch.node_off.data_ptr(), B,
+                                    F, p_ref.data_ptr(), _stream()), "stats")
+    # fused
+    G = torch.full((N, F), float("nan"), device=DEV)
+    p_f = torch.full((B, 2, F), float("nan"), dtype=torch.float64, device=DEV)
+    part_f = torch.empty_like(part_e)
+    a = batch.arena
+    check(lib.gnm_agg_bwd_stats(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
+                                batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, dp.data_ptr(), F,
+                                G.data_ptr(), F, F, epsp, average, int(not learn_eps),
+                                hf.data_ptr() if learn_eps else None, F if learn_eps else 0,
+                                part_f.data_ptr() if learn_eps else None, Z.data_ptr(), F, sc.data_ptr(),
+                                sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), dpool.data_ptr(), F, graph_avg,
+                                dsc1.data_ptr() if disc else None, Ul.data_ptr() if disc else None,
+                                U.stride(0) if disc else 0, invd.data_ptr() if disc else None,
+                                s2.data_ptr() if disc else None, p_f.data_ptr(), _stream()), "agg_bwd_stats")
+    assert_close(G.cpu().numpy(), G_ref.cpu().numpy(), rtol=TOL, what="G")
+    fl = 1e-3 * float(G_ref.abs().sum(0).max())
+    assert_close(p_f.cpu().numpy(), p_ref.cpu().numpy(), rtol=TOL, what="BN-backward partial sums", floor=fl)
+    if learn_eps:
+        assert torch.equal(part_f, part_e)                   # the d-eps partials are untouched by the fusion
+    # shapes it does not cover are refused
+    assert lib.gnm_agg_bwd_stats(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
+                                 batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                 batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, dp.data_ptr(), F,
+                                 G.data_ptr(), F, 32, epsp, average, int(not learn_eps), None, 0, None, Z.data_ptr(), F,
+                                 sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), None, 0, 0, None, None, 0,
+                                 None, None, p_f.data_ptr(), _stream()) == -2
+
+
 LIN_CASES = [(1000, 64, 64), (1000, 7, 64), (33, 64, 64), (1, 5, 32), (777, 128, 128), (500, 32, 32),
              (640, 400, 64), (300, 64, 7), (300, 64, 128), (257, 16, 96), (4096, 64, 64)]
 
