@@ -41,6 +41,9 @@ SIGNATURES = {
     "gnm_bn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _ll, _i, _p]),
     "gnm_disc_score_fwd": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p]),
     "gnm_disc_score_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p]),
+    "gnm_loss_workspace_doubles": (_ll, [_ll]),
+    "gnm_loss_ce_bce": (_i, [_p, _i, _p, _i, _i, _p, _p, _ll, _ll, _f, _p, _p, _i, _p, _p, _p]),
+    "gnm_adam_step": (_i, [_p, _p, _p, _p, _ll, _p, _p, _p]),
 }
 
 

@@ -17,10 +17,16 @@ from .arena import StaticBatch
 
 
 class CapturedTrainStep:
-    def __init__(self, model, template_batch, loss_fn, zero_grad=None, warmup=3):
+    def __init__(self, model, template_batch, loss_fn, zero_grad=None, warmup=3, post_backward=None, preserve=()):
         """loss_fn(c_logit, d_logit, labels) -> scalar loss.  zero_grad(): clears the
-        gradient buffers (default: model.zero_grad(set_to_none=False))."""
+        gradient buffers (default: model.zero_grad(set_to_none=False)).  post_backward(): extra
+        capturable work recorded after backward (e.g. a fused optimizer step).  The warm-up passes
+        are real steps on the template batch: parameters, BatchNorm buffers and every tensor in
+        `preserve` (optimizer state) are put back afterwards, so construction has no side effect."""
         self.model = model
+        self._post = post_backward
+        keep = [t for t in model.state_dict().values()] + list(preserve)
+        snapshot = [t.clone() for t in keep]
         dev = template_batch.node_off.device
         self.static = StaticBatch(template_batch)
         B = template_batch.B
@@ -42,6 +48,9 @@ class CapturedTrainStep:
         # thread_local: other threads of the process (e.g. RCCL's watchdog) keep issuing HIP calls
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss = self._step()
+        with torch.no_grad():
+            for t, s0 in zip(keep, snapshot):
+                t.copy_(s0)
         torch.cuda.synchronize()
 
     def _step(self):
@@ -49,6 +58,8 @@ class CapturedTrainStep:
         c_logit, d_logit = self.model.forward_batch(self.static.batch, perm=self.perm)
         loss = self._loss_fn(c_logit, d_logit, self.labels)
         loss.backward()
+        if self._post is not None:
+            self._post()
         return loss
 
     def run(self, batch, labels, perm=None):

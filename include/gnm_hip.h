@@ -160,6 +160,27 @@ int gnm_disc_score_bwd(const float* const* hptrs_host, int ldh, int L, int H, co
                        const int32_t* perm_rows, const int32_t* node_off, int N, int B, float* dU, int ldu,
                        float* s2sum, void* stream);
 
+/* ---- train-step tail ----------------------------------------------
+ * gnm_loss_ce_bce replaces, in the reference's train() (main.py:16-17, 32-37):
+ *     c_loss = CrossEntropyLoss()(c_logit, c_labels)
+ *     d_loss = BCEWithLogitsLoss()(d_logit, d_labels)
+ *     loss   = c_loss + beta * d_loss                 and the first step of loss.backward()
+ * loss3 = {loss, c_loss, d_loss}; dC [B,C] = d loss / d c_logit; dD [M] = d loss / d d_logit (either may be
+ * NULL).  labels: int64 [B], each in [0,C).  d_target [M] or NULL = the reference's labels (first n_pos
+ * entries 1, the rest 0; main.py:32).  workspace: gnm_loss_workspace_doubles(M) doubles. */
+long long gnm_loss_workspace_doubles(long long M);
+int gnm_loss_ce_bce(const float* c_logit, int ldc, const long long* labels, int B, int C, const float* d_logit,
+                    const float* d_target, long long M, long long n_pos, float beta, float* loss3, float* dC,
+                    int lddc, float* dD, double* workspace, void* stream);
+/* gnm_adam_step replaces optimizer.step() of optim.Adam(model.parameters(), lr) (main.py:136, 39-41) on a flat
+ * fp32 parameter buffer: torch.optim.Adam's default update (no AMSGrad, L2 weight decay).
+ * hyper: DEVICE array of 6 doubles {lr, beta1, beta2, eps, weight_decay, grad_scale} (grad is multiplied by
+ * grad_scale first: 1/world after a sum all-reduce); step: DEVICE int32, updates done so far, incremented on
+ * the stream after the update -- so the call is hipGraph-capturable and StepLR (main.py:137,153) is a write
+ * of hyper[0] between replays. */
+int gnm_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                  const double* hyper, int32_t* step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

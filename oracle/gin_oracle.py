@@ -356,6 +356,43 @@ class OracleGIN:
         return dict(loss=loss, c_loss=c_loss, d_loss=d_loss, c_logit=c_logit, d_logit=d_logit,
                     grads=grads, cache=cache)
 
+    # -- optimizer (main.py:136-137, 39-41, 153) ------------------------------------
+    def param_names(self):
+        """trainable tensors, i.e. everything in the state dict that is not a BatchNorm buffer"""
+        return [k for k in self.p if not (k.endswith("running_mean") or k.endswith("running_var")
+                                          or k.endswith("num_batches_tracked"))]
+
+    def adam_step(self, grads, opt_state, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        """optimizer.step() of optim.Adam(model.parameters(), lr) (main.py:136, 41).  torch.optim.Adam
+        (third party) restated from its documented update: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+        p -= lr / (1-b1^t) * m / (sqrt(v) / sqrt(1-b2^t) + eps).  opt_state: {'t': int, name: (m, v)}."""
+        t = opt_state["t"] = opt_state.get("t", 0) + 1
+        b1, b2 = betas
+        for k in self.param_names():
+            if k not in grads:
+                continue
+            g = np.asarray(grads[k], dtype=self.dtype).reshape(self.p[k].shape)
+            if weight_decay:
+                g = g + weight_decay * self.p[k]
+            m, v = opt_state.get(k, (np.zeros_like(self.p[k]), np.zeros_like(self.p[k])))
+            m = (m + (g - m) * self.dtype.type(1 - b1)).astype(self.dtype)
+            v = (v * self.dtype.type(b2) + self.dtype.type(1 - b2) * g * g).astype(self.dtype)
+            denom = np.sqrt(v) / self.dtype.type(np.sqrt(1 - b2 ** t)) + self.dtype.type(eps)
+            self.p[k] = (self.p[k] - self.dtype.type(lr / (1 - b1 ** t)) * (m / denom)).astype(self.dtype)
+            opt_state[k] = (m, v)
+        return opt_state
+
+    def train_trajectory(self, batch, perms, lr, beta=0.05, step_size=None, gamma=1.0):
+        """len(perms) steps of the reference's train() body (main.py:29-41) on one fixed batch, with
+        StepLR(step_size, gamma) stepped after every optimizer step.  Returns [[loss, c_loss, d_loss], ...]."""
+        opt_state, losses = {}, []
+        for s, perm in enumerate(perms):
+            r = self.train_step_grads(batch, perm, beta=beta)
+            losses.append([float(r["loss"]), float(r["c_loss"]), float(r["d_loss"])])
+            cur = lr * (gamma ** (s // step_size)) if step_size else lr
+            self.adam_step(r["grads"], opt_state, cur)
+        return np.array(losses), opt_state
+
     def latent(self, batch, perm):
         """forward(..., latent=True), graphcnn.py:248-249."""
         _, _, cache = self.forward(batch, perm, training=False)

@@ -31,7 +31,8 @@ TRUE_SHAPE_GRAD_RTOL = 5e-3
 
 def golden_cases(prefix=""):
     files = sorted(glob.glob(os.path.join(GOLDEN_DIR, prefix + "*.npz")))
-    return [os.path.basename(f)[:-4] for f in files if not os.path.basename(f).startswith("state_")]
+    # state_*: seeded state dicts; train_*: training trajectories (tests/test_oracle_train_golden.py)
+    return [os.path.basename(f)[:-4] for f in files if not os.path.basename(f).startswith(("state_", "train_"))]
 
 
 def load_case(name):
