@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--no-learn-eps", action="store_true")
     ap.add_argument("--no-direct-grads", action="store_true",
                     help="let autograd accumulate parameter gradients instead of writing them into the flat buffer")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: BatchNorm over the union batch (20 tiny all-reduces per step, eager launches)")
     ap.add_argument("--torch-loss", action="store_true",
                     help="compute CE + 0.05*BCE with torch ops (as main.py does) instead of the fused loss kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,7 +150,7 @@ def main():
                            dev).to(dev)
     state_cpu = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
     model.train()
-    dp = DataParallelGIN(model, direct_grads=not args.no_direct_grads)
+    dp = DataParallelGIN(model, direct_grads=not args.no_direct_grads, sync_bn=args.sync_bn and world > 1)
     dp.broadcast_parameters()
     arena = model.arena()
     gids_all = np.array([arena.add(g) for g in pool], dtype=np.int64)
@@ -176,7 +178,7 @@ def main():
         def loss_fn(c_logit, d_logit, lab):        # the same two losses, one fused pass (gnm_loss_ce_bce)
             return infomax_loss(c_logit, d_logit, lab, 0.05)[0]
 
-    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    use_graph = (args.graph == "on" or (args.graph == "auto" and world > 1)) and not args.sync_bn
     captured = None
     if use_graph:
         from gnm.graphs import CapturedTrainStep

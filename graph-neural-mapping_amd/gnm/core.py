@@ -96,6 +96,10 @@ class GinSpec:
         # gradient straight into these tensors (OVERWRITING them) and autograd gets None, instead of
         # fresh tensors that AccumulateGrad then adds into .grad with ~50 tiny kernels per step.
         self.grad_sink = None
+        # Optional cross-rank BatchNorm (SURVEY.md 8(e) "sync_bn"): an object with all_reduce(tensor) (SUM over
+        # the data-parallel group) and global_count(n).  When set, train-mode BatchNorm normalises with the
+        # statistics of the UNION batch, so W ranks reproduce one process on the whole batch.  Eager launches only.
+        self.sync_bn = None
 
 
 def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None):
@@ -135,7 +139,7 @@ def _linear_wide(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
 
 
 class _LinSave:
-    __slots__ = ("x_in", "pro", "z", "scale", "shift", "mean", "rstd", "K", "H")
+    __slots__ = ("x_in", "pro", "z", "scale", "shift", "mean", "rstd", "K", "H", "Ng")
 
 
 def encoder_forward(spec, batch, X, P, training, update_running):
@@ -149,6 +153,8 @@ def encoder_forward(spec, batch, X, P, training, update_running):
     g_f = torch.empty((B, L * H), **f32)
     hidden, saved = [], []
     h = X
+    sync = spec.sync_bn if training else None
+    Ng = sync.global_count(N, dev) if sync is not None else N        # rows of the union batch
     for l in range(L):
         F_l = h.shape[1]
         pooled = torch.empty((N, F_l), **f32)
@@ -169,7 +175,12 @@ def encoder_forward(spec, batch, X, P, training, update_running):
             sv = _LinSave()
             sv.x_in, sv.pro, sv.z, sv.K, sv.H = x_in, pro, z, K, Hk
             sv.scale, sv.shift, sv.mean, sv.rstd = (torch.empty(Hk, **f32) for _ in range(4))
-            check(lib.gnm_bn_finalize(ptr(stats), grid, Hk, N, P[bn + ".weight"].data_ptr(),
+            sv.Ng = Ng
+            if sync is not None:
+                stats = stats.sum(0, keepdim=True)            # [1,2,Hk] column sum / sum of squares (fp64)
+                sync.all_reduce(stats)
+                grid = 1
+            check(lib.gnm_bn_finalize(ptr(stats), grid, Hk, Ng, P[bn + ".weight"].data_ptr(),
                                       P[bn + ".bias"].data_ptr(), P[bn + ".running_mean"].data_ptr(),
                                       P[bn + ".running_var"].data_ptr(),
                                       P[bn + ".num_batches_tracked"].data_ptr(), BN_MOMENTUM, BN_EPS,
@@ -365,6 +376,16 @@ class GinInfoMaxFn(torch.autograd.Function):
                                               sv.rstd.data_ptr(), int(ctx.training), dgamma.data_ptr(),
                                               dbeta.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), st),
                       "gnm_bn_bwd_finalize")
+                if spec.sync_bn is not None and ctx.training:
+                    # d gamma / d beta stay LOCAL sums (the gradient all-reduce averages them, as for every other
+                    # parameter); the two means inside dZ = cA (G - m1 - xhat m2) are over the union batch
+                    red = part.view(-1, 2, Hk)[:nblk].sum(0, keepdim=True)
+                    spec.sync_bn.all_reduce(red)
+                    scratch = torch.empty((2, Hk), **f32)
+                    check(lib.gnm_bn_bwd_finalize(red.data_ptr(), 1, Hk, sv.Ng, P[bn + ".weight"].data_ptr(),
+                                                  sv.rstd.data_ptr(), 1, scratch[0].data_ptr(),
+                                                  scratch[1].data_ptr(), cA.data_ptr(), m1.data_ptr(),
+                                                  m2.data_ptr(), st), "gnm_bn_bwd_finalize")
                 if sink is None:
                     grads[bn + ".weight"], grads[bn + ".bias"] = dgamma, dbeta
                 wname = f"mlps.{l}.linear" if m == 1 else f"mlps.{l}.linears.{k}"

@@ -42,11 +42,31 @@ class FlatParams:
             off += n
 
 
+class _BnSync:
+    """GinSpec.sync_bn: SUM over the data-parallel group of the BatchNorm column sums (2*H doubles per
+    BatchNorm, forward and backward: 20 tiny collectives per step at L = 5, m = 2) -- SURVEY.md 8(e)."""
+
+    def __init__(self, group):
+        self.group = group
+
+    def all_reduce(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def global_count(self, n, device):
+        t = torch.tensor([n], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())            # one host sync per forward; sync_bn is the parity mode, not the fast one
+
+
 class DataParallelGIN:
     """Wraps a GIN_InfoMaxReg replica.  broadcast_parameters() once, then per step:
-    zero_grad(); loss(forward(local shard)).backward(); allreduce_gradients()."""
+    zero_grad(); loss(forward(local shard)).backward(); allreduce_gradients().
 
-    def __init__(self, model, process_group=None, direct_grads=True):
+    sync_bn=True: train-mode BatchNorm uses union-batch statistics (all ranks then reproduce a single
+    process on the whole batch, for equal shard sizes); default False = per-rank statistics, the usual
+    DistributedDataParallel semantics and the scaling configuration."""
+
+    def __init__(self, model, process_group=None, direct_grads=True, sync_bn=False):
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -65,6 +85,10 @@ class DataParallelGIN:
                 off += p.numel()
             spec.grad_sink = sink
             self.direct = True
+        if sync_bn:
+            if spec is None or self.world == 1:
+                raise ValueError("sync_bn needs a GIN_InfoMaxReg model and an initialised process group (world > 1)")
+            spec.sync_bn = _BnSync(process_group)
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
