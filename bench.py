@@ -190,9 +190,11 @@ def main():
             dp.fp.zero_grad()
     perms = [np.random.permutation(B) for _ in range(nsteps)]     # graphcnn.py:199, one draw per forward
 
+    use_captured = captured is not None
+
     def step(i):
         bt, lab = batches[i]
-        if captured is not None:
+        if use_captured:
             loss = captured.run(bt, lab, perms[i])
         else:
             dp.zero_grad()
@@ -204,6 +206,26 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if captured is not None and args.graph == "auto" and world > 1:
+        # both launch modes are bitwise equivalent; keep whichever is faster together with this job's
+        # collective (decided once, on untimed steps, identically on every rank)
+        def trial(flag, n=3):
+            nonlocal use_captured
+            use_captured = flag
+            step(0)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(n):
+                step(i % nsteps)
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        t_graph, t_eager = trial(True), trial(False)
+        use_captured = t_graph <= t_eager
+    if not use_captured:
+        captured = None
     if not args.no_kernel_timer and captured is None:
         core.TIMER = core.KernelTimer(None if args.time_all_kernels else ("agg_fwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
     if world > 1:
