@@ -109,27 +109,41 @@ extern "C" int gnm_disc_score_fwd(const float* const* hptrs, int ldh, int L, int
 // Backward wrt U (and the per-graph sum of the negative-branch gradient):
 //   s2sum[g]  = sum_{v in g} dD[N + v]
 //   dU[g, l*H + c] = sum_{v in g} dD[v] * h_l[v, c] + s2sum[g] * h_l[perm_rows[g], c]
-// (the gradient wrt n_f itself is folded into gnm_bn_relu_bwd_stats).
+// (the gradient wrt n_f itself is folded into gnm_bn_relu_bwd_stats).  Optional by-products for the caller:
+//   dsum[g] = sum_{v in g} (dD[v] + dD[N + v])   (their sum over g is the Bilinear bias gradient)
+//   inv_perm[perm_rows[g]] = g                     (who uses graph g's first-rows as negatives)
 __global__ void __launch_bounds__(256) gnm_disc_du_kernel(const HPtrs hp, int ldh, int L, int H,
                                                           const float* __restrict__ dD,
                                                           const int32_t* __restrict__ perm_rows,
                                                           const int32_t* __restrict__ node_off, int N,
                                                           float* __restrict__ dU, int ldu,
-                                                          float* __restrict__ s2sum) {
+                                                          float* __restrict__ s2sum, float* __restrict__ dsum,
+                                                          int32_t* __restrict__ inv_perm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* red = reinterpret_cast<float4*>(smem);     // [RP][H4]
-    __shared__ float wsum[4];
+    __shared__ float wsum[8];
     const int g = blockIdx.x;
     const int row0 = node_off[g];
     const int n = node_off[g + 1] - row0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float s = 0.f;
-    for (int r = tid; r < n; r += 256) s += dD[(size_t)N + row0 + r];
+    float s = 0.f, s1 = 0.f;
+    for (int r = tid; r < n; r += 256) {
+        s += dD[(size_t)N + row0 + r];
+        s1 += dD[(size_t)row0 + r];
+    }
     s = wave_sum(s);
-    if (lane == 0) wsum[wave] = s;
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+        wsum[wave] = s;
+        wsum[4 + wave] = s1;
+    }
     __syncthreads();
     const float s2 = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-    if (tid == 0) s2sum[g] = s2;
+    if (tid == 0) {
+        s2sum[g] = s2;
+        if (dsum) dsum[g] = s2 + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]));
+        if (inv_perm) inv_perm[perm_rows[g]] = g;
+    }
     const int H4 = H >> 2;
     const int RP = 256 / H4;
     const int rg = tid / H4, c4 = tid - rg * H4;
@@ -163,7 +177,7 @@ __global__ void __launch_bounds__(256) gnm_disc_du_kernel(const HPtrs hp, int ld
 
 extern "C" int gnm_disc_score_bwd(const float* const* hptrs, int ldh, int L, int H, const float* dD,
                                   const int32_t* perm_rows, const int32_t* node_off, int N, int B, float* dU, int ldu,
-                                  float* s2sum, void* stream) {
+                                  float* s2sum, float* dsum, int32_t* inv_perm, void* stream) {
     if (B <= 0) return GNM_OK;
     if (L <= 0 || L > GNM_MAX_LAYERS || H <= 0 || (H & 3) || H > 1024 || (ldh & 3) || (ldu & 3))
         return GNM_ERR_BAD_ARG;
@@ -172,7 +186,7 @@ extern "C" int gnm_disc_score_bwd(const float* const* hptrs, int ldh, int L, int
     const int H4 = H >> 2, RP = 256 / H4;
     hipLaunchKernelGGL(gnm_disc_du_kernel, dim3(B), dim3(256), (size_t)RP * H4 * 16,
                        reinterpret_cast<hipStream_t>(stream), hp, ldh, L, H, dD, perm_rows, node_off, N, dU, ldu,
-                       s2sum);
+                       s2sum, dsum, inv_perm);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }

@@ -348,6 +348,40 @@ __global__ void __launch_bounds__(1024) gnm_sum_partials_kernel(const double* __
     if (tid == 0) *out = (float)lds[0];
 }
 
+// the same for several independent sets in one launch (the d eps of all layers): set k = partial[k*stride .. +counts[k])
+struct SumCounts {
+    int n[16];
+};
+__global__ void __launch_bounds__(1024) gnm_sum_partials_multi_kernel(const double* __restrict__ partial,
+                                                                      long long stride, const SumCounts counts,
+                                                                      float* __restrict__ out) {
+    __shared__ double lds[1024];
+    const int tid = threadIdx.x, k = blockIdx.x;
+    const double* p = partial + (long long)k * stride;
+    const int count = counts.n[k];
+    double s = 0.0;
+    for (int i = tid; i < count; i += 1024) s += p[i];
+    lds[tid] = s;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) lds[tid] += lds[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) out[k] = (float)lds[0];
+}
+
+extern "C" int gnm_sum_partials_multi(const double* partial, long long stride, const int* counts_host, int nsets,
+                                      float* out, void* stream) {
+    if (nsets <= 0) return GNM_OK;
+    if (nsets > 16 || !partial || !counts_host || !out) return GNM_ERR_BAD_ARG;
+    SumCounts c;
+    for (int k = 0; k < 16; ++k) c.n[k] = k < nsets ? counts_host[k] : 0;
+    hipLaunchKernelGGL(gnm_sum_partials_multi_kernel, dim3(nsets), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
+                       partial, stride, c, out);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 extern "C" int gnm_sum_partials(const double* partial, int count, float* out, void* stream) {
     hipLaunchKernelGGL(gnm_sum_partials_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
                        partial, count, out);

@@ -116,6 +116,61 @@ extern "C" int gnm_loss_ce_bce(const float* c_logit, int ldc, const long long* l
     return GNM_OK;
 }
 
+// Gradients only, scaled by the upstream gradient *gscale_dev (a device scalar: what autograd hands to backward),
+// in ONE launch: blocks [0, nblk) the BCE part, the last block the cross-entropy part.
+__global__ void __launch_bounds__(kBceThreads) gnm_loss_grad_kernel(const float* __restrict__ c_logit, int ldc,
+                                                                    const long long* __restrict__ labels, int B, int C,
+                                                                    const float* __restrict__ x,
+                                                                    const float* __restrict__ target, long long M,
+                                                                    long long n_pos, float beta,
+                                                                    const float* __restrict__ gscale_dev,
+                                                                    float* __restrict__ dC, int lddc,
+                                                                    float* __restrict__ dD, int nblk) {
+    const float up = gscale_dev ? *gscale_dev : 1.f;
+    if ((int)blockIdx.x < nblk) {
+        const float gscale = up * (beta / (float)M);
+        const long long base = (long long)blockIdx.x * (kBceThreads * kBcePerThread);
+#pragma unroll
+        for (int j = 0; j < kBcePerThread; ++j) {
+            const long long i = base + (long long)j * kBceThreads + threadIdx.x;
+            if (i < M) {
+                const float v = x[i];
+                const float y = target ? target[i] : (i < n_pos ? 1.f : 0.f);
+                const float e = expf(-fabsf(v));
+                const float sig = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+                dD[i] = gscale * (sig - y);
+            }
+        }
+        return;
+    }
+    if (!dC) return;
+    const float invB = B > 0 ? up / (float)B : 0.f;
+    for (int r = threadIdx.x; r < B; r += kBceThreads) {
+        const float* row = c_logit + (long long)r * ldc;
+        float mx = row[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+        const float inv = 1.f / se;
+        const int lab = (int)labels[r];
+        for (int c = 0; c < C; ++c)
+            dC[(long long)r * lddc + c] = (expf(row[c] - mx) * inv - (c == lab ? 1.f : 0.f)) * invB;
+    }
+}
+
+extern "C" int gnm_loss_ce_bce_grad(const float* c_logit, int ldc, const long long* labels, int B, int C,
+                                    const float* d_logit, const float* d_target, long long M, long long n_pos,
+                                    float beta, const float* gscale_dev, float* dC, int lddc, float* dD,
+                                    void* stream) {
+    if (B < 0 || C < 1 || M < 0 || (B > 0 && dC && (!c_logit || !labels)) || (M > 0 && (!d_logit || !dD)))
+        return GNM_ERR_BAD_ARG;
+    const int nblk = M > 0 ? (int)gnm_loss_workspace_doubles(M) : 0;
+    hipLaunchKernelGGL(gnm_loss_grad_kernel, dim3(nblk + 1), dim3(kBceThreads), 0, reinterpret_cast<hipStream_t>(stream),
+                       c_logit, ldc, labels, B, C, d_logit, d_target, M, n_pos, beta, gscale_dev, dC, lddc, dD, nblk);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Adam over a flat parameter buffer.  hyper (device, 6 doubles -- Python floats, as torch.optim holds them): lr,
 // beta1, beta2, eps, weight_decay, grad_scale;

@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libgnm_hip.so")
-SOURCES = ["agg.hip", "linear.hip", "norm.hip", "disc.hip", "tail.hip", "host.cpp"]
+SOURCES = ["agg.hip", "linear.hip", "norm.hip", "disc.hip", "head.hip", "tail.hip", "host.cpp"]
 
 
 def _hipcc():

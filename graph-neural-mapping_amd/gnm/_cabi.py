@@ -24,6 +24,7 @@ SIGNATURES = {
     "gnm_agg_slice_width": (_i, [_i, _i]),
     "gnm_agg_num_partials": (_i, [_i, _i, _i]),
     "gnm_sum_partials": (_i, [_p, _i, _p, _p]),
+    "gnm_sum_partials_multi": (_i, [_p, _ll, _p, _i, _p, _p]),
     "gnm_linear_grid": (_i, [_i]),
     "gnm_linear_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),
     "gnm_wgrad_grid": (_i, [_i]),
@@ -40,9 +41,12 @@ SIGNATURES = {
     "gnm_bn_bwd_finalize": (_i, [_p, _i, _i, _ll, _p, _p, _i, _p, _p, _p, _p, _p, _p]),
     "gnm_bn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _p, _p, _p, _p, _p, _i, _ll, _i, _p]),
     "gnm_disc_score_fwd": (_i, [_p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p]),
-    "gnm_disc_score_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p]),
+    "gnm_disc_score_bwd": (_i, [_p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "gnm_head_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
+    "gnm_head_bwd": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
     "gnm_loss_workspace_doubles": (_ll, [_ll]),
     "gnm_loss_ce_bce": (_i, [_p, _i, _p, _i, _i, _p, _p, _ll, _ll, _f, _p, _p, _i, _p, _p, _p]),
+    "gnm_loss_ce_bce_grad": (_i, [_p, _i, _p, _i, _i, _p, _p, _ll, _ll, _f, _p, _p, _i, _p, _p]),
     "gnm_adam_step": (_i, [_p, _p, _p, _p, _ll, _p, _p, _p]),
 }
 

@@ -205,6 +205,9 @@ def _hptr_array(hidden):
     return arr
 
 
+_ptr_array = _hptr_array
+
+
 class GinInfoMaxFn(torch.autograd.Function):
     """(X, *params) -> (c_logit [B,C], d_logit [2N,1], g_f [B,L*H])."""
 
@@ -226,30 +229,49 @@ class GinInfoMaxFn(torch.autograd.Function):
         X = X.contiguous()
         hidden, g_f, saved = encoder_forward(spec, batch, X, P, training, update_running=training)
         H = hidden[0].shape[1]
-        # classifier (graphcnn.py:224-231): L tiny [B,H] x [H,C] products + dropout, batched into
-        # one bmm / one dropout call on an [L,B,C] tensor (torch on device: plumbing-sized work)
-        Wp = torch.stack([P[f"linears_prediction.{l}.weight"] for l in range(L)])        # [L,C,H]
-        bp = torch.stack([P[f"linears_prediction.{l}.bias"] for l in range(L)])          # [L,C]
-        G3 = g_f.view(B, L, H).transpose(0, 1)                                           # [L,B,H] view
-        lg = torch.baddbmm(bp.unsqueeze(1), G3, Wp.transpose(1, 2))                      # [L,B,C]
+        # classifier head (graphcnn.py:224-231) and sigmoid(g_f) (:239): one launch (csrc/head.hip)
+        wps = [P[f"linears_prediction.{l}.weight"] for l in range(L)]
+        bps = [P[f"linears_prediction.{l}.bias"] for l in range(L)]
+        Cn = wps[0].shape[0]
         masks = None
         if training and dropout_p > 0:
-            masks = F.dropout(torch.ones_like(lg), dropout_p, True)                      # F.dropout at :230
-            lg = lg * masks
-        c_logit = lg.sum(0)
+            masks = F.dropout(torch.ones((L, B, Cn), dtype=torch.float32, device=X.device), dropout_p, True)  # :230
+        c_logit = torch.empty((B, Cn), dtype=torch.float32, device=X.device)
+        c = torch.empty_like(g_f) if want_disc else None
+        fused_head = all(w.is_contiguous() for w in wps) and all(b_.is_contiguous() for b_ in bps)
+        if fused_head:
+            rc = lib.gnm_head_fwd(g_f.data_ptr(), g_f.stride(0), B, L, H, Cn, _ptr_array(wps), _ptr_array(bps),
+                                  ptr(masks), c_logit.data_ptr(), c_logit.stride(0), ptr(c),
+                                  c.stride(0) if c is not None else 0, _stream())
+            if rc == -2:
+                fused_head = False
+            else:
+                check(rc, "gnm_head_fwd")
+        Wp = None
+        if not fused_head:          # shapes outside the head kernel (C*H > 256): batched matrix products
+            Wp = torch.stack(wps)                                                            # [L,C,H]
+            G3 = g_f.view(B, L, H).transpose(0, 1)                                           # [L,B,H] view
+            lg = torch.baddbmm(torch.stack(bps).unsqueeze(1), G3, Wp.transpose(1, 2))        # [L,B,C]
+            if masks is not None:
+                lg = lg * masks
+            c_logit = lg.sum(0)
+            if want_disc:
+                c = torch.sigmoid(g_f)
         d_logit = None
-        c = U = perm_rows = None
+        U = perm_rows = None
         if want_disc:
             if not batch.equal_n:
                 raise RuntimeError("Discriminator expands each graph summary N//B times (discriminator.py:24): "
                                    "all graphs of a batch must have the same number of nodes")
-            c = torch.sigmoid(g_f)                                            # graphcnn.py:239
             Wd = P["disc.f_k.weight"][0]
             U = c @ Wd.t()                                                    # U[g] = W c_g
             if torch.is_tensor(perm) and perm.is_cuda:      # graph-capture safe: already on the device
                 perm_rows = perm.to(torch.int32)
             else:
-                perm_rows = torch.as_tensor(perm, dtype=torch.int32).to(X.device)  # row index = perm[g] (:198-201,242)
+                # row index = perm[g] (:198-201,242).  Pinned staging + async copy: a pageable H2D copy would make
+                # the host wait until the stream has drained everything launched so far, and the GPU then
+                # idles while the host catches up
+                perm_rows = torch.as_tensor(perm, dtype=torch.int32).pin_memory().to(X.device, non_blocking=True)
             d_logit = torch.empty((2 * N, 1), dtype=torch.float32, device=X.device)
             check(lib.gnm_disc_score_fwd(_hptr_array(hidden), hidden[0].stride(0), L, H, U.data_ptr(), U.stride(0),
                                          perm_rows.data_ptr(), P["disc.f_k.bias"].data_ptr(),
@@ -257,6 +279,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                   "gnm_disc_score_fwd")
         ctx.spec, ctx.batch, ctx.names, ctx.P = spec, batch, names, P
         ctx.hidden, ctx.saved, ctx.g_f, ctx.masks, ctx.Wp = hidden, saved, g_f, masks, Wp
+        ctx.fused_head, ctx.wps = fused_head, wps
         ctx.c, ctx.U, ctx.perm_rows, ctx.perm = c, U, perm_rows, perm
         ctx.training, ctx.X = training, X
         ctx.mark_non_differentiable(g_f)
@@ -296,46 +319,76 @@ class GinInfoMaxFn(torch.autograd.Function):
 
         # ---- discriminator (discriminator.py:28-36) --------------------------------
         dsc1 = U = inv_perm = s2sum = None
-        dg_f = None
+        dg_f = T = None
         if dD is not None and ctx.U is not None:
             dD = dD.contiguous().view(-1)
             U, c = ctx.U, ctx.c
             dU = torch.empty_like(U)
             s2sum = torch.empty(B, **f32)
+            dsum = torch.empty(B, **f32)
+            inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
             check(lib.gnm_disc_score_bwd(_hptr_array(hidden), hidden[0].stride(0), L, H, dD.data_ptr(),
                                          ctx.perm_rows.data_ptr(), batch.node_off.data_ptr(), N, B, dU.data_ptr(),
-                                         dU.stride(0), s2sum.data_ptr(), st), "gnm_disc_score_bwd")
+                                         dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(), inv_perm.data_ptr(), st),
+                  "gnm_disc_score_bwd")
             Wd = P["disc.f_k.weight"][0]
-            put("disc.f_k.weight", (dU.t() @ c).unsqueeze(0))
-            put("disc.f_k.bias", dD.sum().reshape(1))
-            dg_f = (dU @ Wd) * c * (1 - c)                                    # sigmoid backward
-            dsc1 = dD                                                         # first N entries = d sc_1
-            inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
-            inv_perm[ctx.perm_rows.long()] = torch.arange(B, dtype=torch.int32, device=dev)
-
-        # ---- classifier (batched over the L layers) --------------------------------------
-        dph_all = None
-        G3 = g_f.view(B, L, H).transpose(0, 1)                                           # [L,B,H]
-        if dC is not None:
-            dlg = dC.unsqueeze(0).expand(L, -1, -1)
-            if ctx.masks is not None:
-                dlg = dlg * ctx.masks
-            dWp = torch.bmm(dlg.transpose(1, 2), G3)                                     # [L,C,H]
-            dbp = dlg.sum(1)                                                             # [L,C]
-            for l in range(L):
-                put(f"linears_prediction.{l}.weight", dWp[l])
-                put(f"linears_prediction.{l}.bias", dbp[l])
-            if dg_f is not None:
-                dph_all = torch.baddbmm(dg_f.view(B, L, H).transpose(0, 1), dlg, ctx.Wp)   # [L,B,H] contiguous
+            if sink is not None:
+                torch.mm(dU.t(), c, out=sink["disc.f_k.weight"][0])
+                torch.sum(dsum, 0, keepdim=True, out=sink["disc.f_k.bias"])
             else:
-                dph_all = torch.bmm(dlg, ctx.Wp)
-        elif dg_f is not None:
-            dph_all = dg_f.view(B, L, H).transpose(0, 1).contiguous()
-        dph = [dph_all[l] if dph_all is not None else None for l in range(L)]
+                grads["disc.f_k.weight"] = (dU.t() @ c).unsqueeze(0)
+                grads["disc.f_k.bias"] = dsum.sum().reshape(1)
+            T = dU @ Wd                                                       # d loss / d sigmoid(g_f)
+            dsc1 = dD                                                         # first N entries = d sc_1
 
-        deps = None
+        # ---- classifier head: d g_f (classifier + sigmoid paths) and the classifier gradients ------------
+        dph = [None] * L
+        if ctx.fused_head and (dC is not None or T is not None):
+            wps = ctx.wps
+            Cn = wps[0].shape[0]
+            dCc = dC.contiguous() if dC is not None else torch.zeros((B, Cn), **f32)
+            dws = [out_like(f"linears_prediction.{l}.weight", wps[l]) for l in range(L)]
+            dbs = [out_like(f"linears_prediction.{l}.bias", wps[l][:, 0]) for l in range(L)]
+            dph_all = torch.empty((B, L * H), **f32)
+            check(lib.gnm_head_bwd(dCc.data_ptr(), dCc.stride(0), ptr(ctx.masks), g_f.data_ptr(), g_f.stride(0),
+                                   ptr(ctx.c), ctx.c.stride(0) if ctx.c is not None else 0, ptr(T),
+                                   T.stride(0) if T is not None else 0, B, L, H, Cn, _ptr_array(wps),
+                                   _ptr_array(dws), _ptr_array(dbs), dph_all.data_ptr(), dph_all.stride(0), st),
+                  "gnm_head_bwd")
+            if sink is None:
+                for l in range(L):
+                    grads[f"linears_prediction.{l}.weight"] = dws[l]
+                    grads[f"linears_prediction.{l}.bias"] = dbs[l]
+            dph = [dph_all[:, l * H:(l + 1) * H] for l in range(L)]
+        elif not ctx.fused_head:
+            if T is not None:
+                dg_f = T * ctx.c * (1 - ctx.c)                                # sigmoid backward
+            dph_all = None
+            G3 = g_f.view(B, L, H).transpose(0, 1)                                           # [L,B,H]
+            if dC is not None:
+                dlg = dC.unsqueeze(0).expand(L, -1, -1)
+                if ctx.masks is not None:
+                    dlg = dlg * ctx.masks
+                dWp = torch.bmm(dlg.transpose(1, 2), G3)                                     # [L,C,H]
+                dbp = dlg.sum(1)                                                             # [L,C]
+                for l in range(L):
+                    put(f"linears_prediction.{l}.weight", dWp[l])
+                    put(f"linears_prediction.{l}.bias", dbp[l])
+                if dg_f is not None:
+                    dph_all = torch.baddbmm(dg_f.view(B, L, H).transpose(0, 1), dlg, ctx.Wp)   # [L,B,H] contiguous
+                else:
+                    dph_all = torch.bmm(dlg, ctx.Wp)
+            elif dg_f is not None:
+                dph_all = dg_f.view(B, L, H).transpose(0, 1).contiguous()
+            dph = [dph_all[l] if dph_all is not None else None for l in range(L)]
+
+        deps = eps_parts = None
+        eps_counts = [0] * L
         if spec.learn_eps:
-            deps = sink["eps"] if sink is not None else torch.zeros(L, **f32)
+            deps = sink["eps"] if sink is not None else torch.empty(L, **f32)
+            # fp64 partials of d eps[l] from the L aggregation backwards, summed by ONE launch at the end
+            eps_stride = max(int(lib.gnm_agg_num_partials(sv_[0].shape[1], batch.n_max, B)) for sv_ in saved)
+            eps_parts = torch.empty((L, eps_stride), dtype=torch.float64, device=dev)
         dH_next = None
         dX = None
         pre_outer = None
@@ -445,7 +498,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                 dh = torch.empty((N, F_l), **f32) if want_dh else None
                 part = None
                 if spec.learn_eps:
-                    part = torch.empty(lib.gnm_agg_num_partials(F_l, batch.n_max, B), dtype=torch.float64, device=dev)
+                    eps_counts[l] = int(lib.gnm_agg_num_partials(F_l, batch.n_max, B))
+                    part = eps_parts[l]
                 eps_ptr = P["eps"].data_ptr() + 4 * l if spec.learn_eps else None
                 fused = False
                 if l > 0 and want_dh:
@@ -477,15 +531,16 @@ class GinInfoMaxFn(torch.autograd.Function):
                 if not fused:
                     _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True,
                          hfwd=h_in if spec.learn_eps else None, deps_partial=part)
-                if spec.learn_eps:
-                    check(lib.gnm_sum_partials(part.data_ptr(), part.numel(), deps.data_ptr() + 4 * l, st),
-                          "gnm_sum_partials")
                 if l > 0:
                     dH_next = dh
                 else:
                     dX = dh
-        if spec.learn_eps and sink is None:
-            grads["eps"] = deps
+        if spec.learn_eps:
+            # layers whose aggregation backward did not run (no incoming gradient) have count 0 -> d eps = 0
+            check(lib.gnm_sum_partials_multi(eps_parts.data_ptr(), eps_parts.stride(0), (C.c_int * L)(*eps_counts), L,
+                                             deps.data_ptr(), st), "gnm_sum_partials_multi")
+            if sink is None:
+                grads["eps"] = deps
         out = [None] * 8 + [dX if need_dx else None]
         for i, name in enumerate(ctx.names):
             out.append(grads.get(name) if ctx.needs_input_grad[9 + i] else None)

@@ -69,6 +69,6 @@ class CapturedTrainStep:
             perm = np.random.permutation(batch.B)
         self.static.load(batch)
         self.labels.copy_(labels, non_blocking=True)
-        self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32), non_blocking=True)
+        self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
         self.graph.replay()
         return self.loss

@@ -4,8 +4,8 @@ launches on flat buffers, and a whole-step driver around them
 What the reference does per step (main.py:29-41) and what runs here instead:
 
     c_loss = CrossEntropyLoss()(c_logit, c_labels)             \\
-    d_loss = BCEWithLogitsLoss()(d_logit, d_labels)              >  infomax_loss(): gnm_loss_ce_bce, 2 launches,
-    loss = c_loss + beta * d_loss                               /   also produces dC / dD for backward
+    d_loss = BCEWithLogitsLoss()(d_logit, d_labels)              >  infomax_loss(): gnm_loss_ce_bce (2 launches) and,
+    loss = c_loss + beta * d_loss                               /   in backward, gnm_loss_ce_bce_grad (1 launch)
     optimizer.zero_grad(); loss.backward()                      -> the model's hand-written backward; gradients
                                                                    land in the flat buffer (GinSpec.grad_sink)
     optimizer.step()            # Adam over ~30 tensors         -> FusedAdam.step(): gnm_adam_step, one launch
@@ -35,8 +35,6 @@ class _InfomaxLossFn(torch.autograd.Function):
         M = d.numel()
         dev = c.device
         loss3 = torch.empty(3, dtype=torch.float32, device=dev)
-        dC = torch.empty_like(c)
-        dD = torch.empty_like(d)
         ws = torch.empty(int(lib.gnm_loss_workspace_doubles(M)), dtype=torch.float64, device=dev)
         tgt = None
         if d_target is not None:
@@ -49,17 +47,25 @@ class _InfomaxLossFn(torch.autograd.Function):
         with _stream_scope():
             check(lib.gnm_loss_ce_bce(c.data_ptr(), c.stride(0), lab.data_ptr(), B, C_, d.data_ptr(),
                                       tgt.data_ptr() if tgt is not None else None, M, int(n_pos), float(beta),
-                                      loss3.data_ptr(), dC.data_ptr(), dC.stride(0), dD.data_ptr(), ws.data_ptr(),
-                                      _stream()), "gnm_loss_ce_bce")
-        ctx.dC, ctx.dD, ctx.dshape = dC, dD, d_logit.shape
+                                      loss3.data_ptr(), None, 0, None, ws.data_ptr(), _stream()), "gnm_loss_ce_bce")
+        ctx.args = (c, d, lab, tgt, int(n_pos), float(beta), d_logit.shape)
         parts = loss3.detach()
         ctx.mark_non_differentiable(parts)
         return loss3[0], parts
 
     @staticmethod
     def backward(ctx, g, _gparts):
-        dC, dD = ctx.dC, ctx.dD
-        return dC.mul_(g), dD.mul_(g).view(ctx.dshape), None, None, None, None
+        c, d, lab, tgt, n_pos, beta, dshape = ctx.args
+        B, C_ = c.shape
+        M = d.numel()
+        g = g.to(torch.float32).contiguous()
+        dC, dD = torch.empty_like(c), torch.empty_like(d)
+        with _stream_scope():      # both gradients, already multiplied by the upstream gradient, in one launch
+            check(lib.gnm_loss_ce_bce_grad(c.data_ptr(), c.stride(0), lab.data_ptr(), B, C_, d.data_ptr(),
+                                           tgt.data_ptr() if tgt is not None else None, M, n_pos, beta, g.data_ptr(),
+                                           dC.data_ptr(), dC.stride(0), dD.data_ptr(), _stream()),
+                  "gnm_loss_ce_bce_grad")
+        return dC, dD.view(dshape), None, None, None, None
 
 
 def infomax_loss(c_logit, d_logit, labels, beta=0.05, d_labels=None):

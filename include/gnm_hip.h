@@ -87,6 +87,9 @@ int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t*
 int gnm_agg_slice_width(int F, int n_max);          /* feature-slice width the kernel will use (0: unsupported) */
 int gnm_agg_num_partials(int F, int n_max, int B);  /* doubles written to deps_partial */
 int gnm_sum_partials(const double* partial, int count, float* out, void* stream);
+/* nsets (<= 16) independent sets in one launch: out[k] = sum of partial[k*stride .. k*stride + counts_host[k]) */
+int gnm_sum_partials_multi(const double* partial, long long stride, const int* counts_host, int nsets, float* out,
+                           void* stream);
 
 /* ---- Linear (mlp.py:25,32-35,43,48,49) on fp32 MFMA ---------------------------------
  * Z[N,H] = f(X)[N,K] W^T + bias with f(x) = x*pro_scale + pro_shift (then ReLU if
@@ -156,9 +159,26 @@ int gnm_bn_bwd_apply(const float* G, int ldg, const float* Z, int ldz, const flo
 int gnm_disc_score_fwd(const float* const* hptrs_host, int ldh, int L, int H, const float* U, int ldu,
                        const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
                        float* d_logit, void* stream);
+/* optional by-products: dsum[g] = sum over graph g of dD (both halves; their total is d bias), and
+ * inv_perm[perm_rows[g]] = g. */
 int gnm_disc_score_bwd(const float* const* hptrs_host, int ldh, int L, int H, const float* dD,
                        const int32_t* perm_rows, const int32_t* node_off, int N, int B, float* dU, int ldu,
-                       float* s2sum, void* stream);
+                       float* s2sum, float* dsum, int32_t* inv_perm, void* stream);
+
+/* ---- graph-level head (graphcnn.py:224-231, 239) --------------------------------------
+ * wp_host / bp_host: HOST arrays of L device pointers to linears_prediction[l].weight ([C,H] row-major) and
+ * .bias.  masks: the dropout masks [L,B,C] (0 or 1/(1-p)) or NULL.
+ * gnm_head_fwd:  c_logit[b,c] = sum_l masks[l,b,c] * (g_f[b, lH:(l+1)H] . W_l[c,:] + b_l[c])   (:230, score_over_layer)
+ *                csig = sigmoid(g_f)                                                           (:239, may be NULL)
+ * gnm_head_bwd:  dph [B, L*H] = d loss / d g_f = classifier path + T * csig * (1 - csig) (T = dU Wd or NULL);
+ *                dwp_host / dbp_host: HOST arrays of L device pointers receiving the classifier gradients.
+ * GNM_ERR_UNSUPPORTED when C*H > 256 or L > 16 (the caller then uses plain matrix products). */
+int gnm_head_fwd(const float* g_f, int ldg, int B, int L, int H, int C, const float* const* wp_host,
+                 const float* const* bp_host, const float* masks, float* c_logit, int ldc, float* csig, int ldcs,
+                 void* stream);
+int gnm_head_bwd(const float* dC, int lddc, const float* masks, const float* g_f, int ldg, const float* csig,
+                 int ldcs, const float* T, int ldt, int B, int L, int H, int C, const float* const* wp_host,
+                 float* const* dwp_host, float* const* dbp_host, float* dph, int lddph, void* stream);
 
 /* ---- train-step tail ----------------------------------------------
  * gnm_loss_ce_bce replaces, in the reference's train() (main.py:16-17, 32-37):
@@ -172,6 +192,11 @@ long long gnm_loss_workspace_doubles(long long M);
 int gnm_loss_ce_bce(const float* c_logit, int ldc, const long long* labels, int B, int C, const float* d_logit,
                     const float* d_target, long long M, long long n_pos, float beta, float* loss3, float* dC,
                     int lddc, float* dD, double* workspace, void* stream);
+/* The same gradients without the loss values, multiplied by the upstream gradient *gscale_dev (device scalar;
+ * NULL = 1): what loss.backward() needs, in one launch. */
+int gnm_loss_ce_bce_grad(const float* c_logit, int ldc, const long long* labels, int B, int C, const float* d_logit,
+                         const float* d_target, long long M, long long n_pos, float beta, const float* gscale_dev,
+                         float* dC, int lddc, float* dD, void* stream);
 /* gnm_adam_step replaces optimizer.step() of optim.Adam(model.parameters(), lr) (main.py:136, 39-41) on a flat
  * fp32 parameter buffer: torch.optim.Adam's default update (no AMSGrad, L2 weight decay).
  * hyper: DEVICE array of 6 doubles {lr, beta1, beta2, eps, weight_decay, grad_scale} (grad is multiplied by

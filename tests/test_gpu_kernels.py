@@ -425,14 +425,84 @@ def test_discriminator_scores_vs_literal_bilinear(B, n, L, H):
     dU = torch.empty((B, LH), device=DEV)
     s2 = torch.empty(B, device=DEV)
     dDd = t(dD)
+    dsum = torch.empty(B, device=DEV)
+    inv_perm = torch.full((B,), -1, dtype=torch.int32, device=DEV)
     check(lib.gnm_disc_score_bwd(hp, H, L, H, dDd.data_ptr(), perm_rows.data_ptr(), node_off.data_ptr(), N, B,
-                                 dU.data_ptr(), LH, s2.data_ptr(), _stream()), "disc bwd")
+                                 dU.data_ptr(), LH, s2.data_ptr(), dsum.data_ptr(), inv_perm.data_ptr(), _stream()),
+          "disc bwd")
     d1, d2 = dD[:N].astype(np.float64), dD[N:].astype(np.float64)
     s2_ref = d2.reshape(B, n).sum(1)
+    assert_close(dsum.cpu().numpy(), s2_ref + d1.reshape(B, n).sum(1), rtol=TOL, what="dsum",
+                 floor=1e-3 * np.abs(dD).max())
+    assert np.array_equal(inv_perm.cpu().numpy(), np.argsort(perm).astype(np.int32))      # bit-exact index structure
     dU_ref = np.stack([(d1[g * n:(g + 1) * n, None] * n_f[g * n:(g + 1) * n]).sum(0) + s2_ref[g] * n_f[perm[g]]
                        for g in range(B)])
     assert_close(s2.cpu().numpy(), s2_ref, rtol=TOL, what="s2sum", floor=1e-3 * np.abs(d2).max())
     assert_close(dU.cpu().numpy(), dU_ref, rtol=TOL, what="dU", floor=1e-3 * np.abs(dU_ref).max())
+
+
+# ------------------------------------------------------------------ graph-level head
+@pytest.mark.parametrize("B,L,H,C,p,with_T", [(3, 5, 64, 2, 0.5, True), (4, 3, 32, 2, 0.0, True), (1, 2, 32, 3, 0.3, False),
+                                              (257, 5, 128, 2, 0.5, True), (5, 1, 20, 7, 0.0, False)])
+def test_head_fwd_bwd_vs_numpy(B, L, H, C, p, with_T):
+    """gnm_head_fwd / gnm_head_bwd against the per-layer restatement of graphcnn.py:224-231,239 in fp64."""
+    import ctypes as CT
+    from gnm._cabi import check, lib, ptr
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    rng = np.random.default_rng(B * 100 + L * 10 + C)
+    LH = L * H
+    g_f = rng.standard_normal((B, LH)).astype(np.float32) * 3
+    Wp = [rng.standard_normal((C, H)).astype(np.float32) for _ in range(L)]
+    bp = [rng.standard_normal(C).astype(np.float32) for _ in range(L)]
+    masks = None
+    if p > 0:
+        masks = ((rng.random((L, B, C)) >= p) / (1 - p)).astype(np.float32)
+    dC = rng.standard_normal((B, C)).astype(np.float32)
+    T = rng.standard_normal((B, LH)).astype(np.float32) if with_T else None
+    tg, tdC = t(g_f), t(dC)
+    tW, tb = [t(w) for w in Wp], [t(b) for b in bp]
+    tm = t(masks) if masks is not None else None
+    tT = t(T) if T is not None else None
+    wp = (CT.c_void_p * L)(*[w.data_ptr() for w in tW])
+    bpp = (CT.c_void_p * L)(*[b.data_ptr() for b in tb])
+    c_logit = torch.empty((B, C), device=DEV)
+    csig = torch.empty((B, LH), device=DEV)
+    check(lib.gnm_head_fwd(tg.data_ptr(), LH, B, L, H, C, wp, bpp, ptr(tm), c_logit.data_ptr(), C, csig.data_ptr(), LH,
+                           _stream()), "head fwd")
+    M = masks.astype(np.float64) if masks is not None else np.ones((L, B, C))
+    g64 = g_f.astype(np.float64)
+    ref_c = sum(M[l] * (g64[:, l * H:(l + 1) * H] @ Wp[l].astype(np.float64).T + bp[l]) for l in range(L))
+    ref_sig = 1 / (1 + np.exp(-g64))
+    assert_close(c_logit.cpu().numpy(), ref_c, rtol=TOL, what="c_logit")
+    assert_close(csig.cpu().numpy(), ref_sig, rtol=TOL, what="sigmoid(g_f)")
+    dW = [torch.full((C, H), 7.0, device=DEV) for _ in range(L)]
+    db = [torch.full((C,), 7.0, device=DEV) for _ in range(L)]
+    dwp = (CT.c_void_p * L)(*[w.data_ptr() for w in dW])
+    dbpp = (CT.c_void_p * L)(*[b.data_ptr() for b in db])
+    dph = torch.empty((B, LH), device=DEV)
+    check(lib.gnm_head_bwd(tdC.data_ptr(), C, ptr(tm), tg.data_ptr(), LH, csig.data_ptr(), LH, ptr(tT), LH, B, L, H, C,
+                           wp, dwp, dbpp, dph.data_ptr(), LH, _stream()), "head bwd")
+    ref_dph = np.zeros((B, LH))
+    for l in range(L):
+        dlg = dC.astype(np.float64) * M[l]
+        ref_dph[:, l * H:(l + 1) * H] = dlg @ Wp[l].astype(np.float64)
+        assert_close(dW[l].cpu().numpy(), dlg.T @ g64[:, l * H:(l + 1) * H], rtol=TOL, what=f"dWp[{l}]")
+        assert_close(db[l].cpu().numpy(), dlg.sum(0), rtol=TOL, what=f"dbp[{l}]", floor=1e-3)
+    if T is not None:
+        ref_dph += T.astype(np.float64) * ref_sig * (1 - ref_sig)
+    assert_close(dph.cpu().numpy(), ref_dph, rtol=TOL, what="dph")
+
+
+def test_head_unsupported_shape_is_reported():
+    import ctypes as CT
+    from gnm._cabi import lib
+    g = torch.zeros((2, 2 * 200), device=DEV)
+    w = [torch.zeros((2, 200), device=DEV) for _ in range(2)]
+    b = [torch.zeros(2, device=DEV) for _ in range(2)]
+    wp = (CT.c_void_p * 2)(*[x.data_ptr() for x in w])
+    bp = (CT.c_void_p * 2)(*[x.data_ptr() for x in b])
+    out = torch.zeros((2, 2), device=DEV)
+    assert lib.gnm_head_fwd(g.data_ptr(), 400, 2, 2, 200, 2, wp, bp, None, out.data_ptr(), 2, None, 0, _stream()) == -2
 
 
 # ------------------------------------------------------------------ full-size properties

@@ -64,6 +64,30 @@ def test_loss_kernel_vs_oracle_and_torch(B, C, M, custom_target):
         assert abs(got[1] - ce) <= 2e-6 * abs(ce) and got[2] == 0.0 and abs(got[0] - got[1]) == 0.0
 
 
+@pytest.mark.parametrize("scale", [1.0, -2.5])
+def test_infomax_loss_autograd_matches_torch_losses_with_upstream_scale(scale):
+    """infomax_loss(...).backward() with an upstream gradient != 1 (gnm_loss_ce_bce_grad reads it from the device)."""
+    from gnm.train import infomax_loss
+    rng = np.random.default_rng(7)
+    B, C, N = 6, 2, 50
+    c0, d0 = t(rng.standard_normal((B, C))), t(2 * rng.standard_normal((2 * N, 1)))
+    lab = t(rng.integers(0, C, B), torch.int64)
+    y = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)]).to(DEV)
+    grads = []
+    for fused in (True, False):
+        c, d = c0.clone().requires_grad_(), d0.clone().requires_grad_()
+        if fused:
+            loss, parts = infomax_loss(c, d, lab, 0.05)
+            assert parts.requires_grad is False and abs(parts[0].item() - loss.item()) == 0.0
+        else:
+            loss = torch.nn.functional.cross_entropy(c, lab) + \
+                0.05 * torch.nn.functional.binary_cross_entropy_with_logits(d, y)
+        (loss * scale).backward()
+        grads.append((loss.item(), c.grad.cpu().numpy(), d.grad.cpu().numpy()))
+    assert abs(grads[0][0] - grads[1][0]) <= 2e-6 * abs(grads[1][0])
+    assert rel_err(grads[0][1], grads[1][1]) <= 2e-6 and rel_err(grads[0][2], grads[1][2]) <= 2e-6
+
+
 def test_loss_kernel_is_reproducible_bitwise():
     from gnm.train import infomax_loss
     rng = np.random.default_rng(0)
