@@ -348,6 +348,37 @@ __global__ void __launch_bounds__(1024) gnm_sum_partials_kernel(const double* __
     if (tid == 0) *out = (float)lds[0];
 }
 
+// d eps[l] when the aggregation backward has no other consumer (layer 0 without input gradients):
+// partial[block] = sum over the block's rows of A[r,:] . B[r,:]  (fp64; summed later with the other layers).
+static constexpr int kDotBlocks = 512;
+__global__ void __launch_bounds__(256) gnm_rowdot_partials_kernel(const float* __restrict__ A, int lda,
+                                                                  const float* __restrict__ Bm, int ldb, long long N,
+                                                                  int F, double* __restrict__ partial) {
+    __shared__ double lds[4];
+    const long long total = N * F;
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / F;
+        const int c = (int)(i - r * F);
+        acc += (double)(A[r * lda + c] * Bm[r * ldb + c]);
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+extern "C" int gnm_rowdot_num_partials(void) { return kDotBlocks; }
+
+extern "C" int gnm_rowdot_partials(const float* A, int lda, const float* Bm, int ldb, long long N, int F,
+                                   double* partial, void* stream) {
+    if (N < 0 || F <= 0 || !partial || (N > 0 && (!A || !Bm))) return GNM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gnm_rowdot_partials_kernel, dim3(kDotBlocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       A, lda, Bm, ldb, N, F, partial);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 // the same for several independent sets in one launch (the d eps of all layers): set k = partial[k*stride .. +counts[k])
 struct SumCounts {
     int n[16];

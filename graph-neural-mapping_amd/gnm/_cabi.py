@@ -24,6 +24,8 @@ SIGNATURES = {
     "gnm_agg_slice_width": (_i, [_i, _i]),
     "gnm_agg_num_partials": (_i, [_i, _i, _i]),
     "gnm_sum_partials": (_i, [_p, _i, _p, _p]),
+    "gnm_rowdot_num_partials": (_i, []),
+    "gnm_rowdot_partials": (_i, [_p, _i, _p, _i, _ll, _i, _p, _p]),
     "gnm_sum_partials_multi": (_i, [_p, _ll, _p, _i, _p, _p]),
     "gnm_linear_grid": (_i, [_i]),
     "gnm_linear_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),

@@ -387,7 +387,8 @@ class GinInfoMaxFn(torch.autograd.Function):
         if spec.learn_eps:
             deps = sink["eps"] if sink is not None else torch.empty(L, **f32)
             # fp64 partials of d eps[l] from the L aggregation backwards, summed by ONE launch at the end
-            eps_stride = max(int(lib.gnm_agg_num_partials(sv_[0].shape[1], batch.n_max, B)) for sv_ in saved)
+            eps_stride = max([int(lib.gnm_agg_num_partials(sv_[0].shape[1], batch.n_max, B)) for sv_ in saved] +
+                             [int(lib.gnm_rowdot_num_partials())])
             eps_parts = torch.empty((L, eps_stride), dtype=torch.float64, device=dev)
         dH_next = None
         dX = None
@@ -528,7 +529,14 @@ class GinInfoMaxFn(torch.autograd.Function):
                         pre_outer = (dh, spart, B)
                     elif rc != -2:
                         check(rc, "gnm_agg_bwd_stats")
-                if not fused:
+                if not fused and dh is None:
+                    # nothing below consumes d h: only d eps[l] = sum dpooled . h is needed -- a flat dot product
+                    eps_counts[l] = int(lib.gnm_rowdot_num_partials())
+                    with _timed("deps_dot_F%d" % F_l, N=N, F=F_l):
+                        check(lib.gnm_rowdot_partials(dpooled.data_ptr(), dpooled.stride(0), h_in.data_ptr(),
+                                                      h_in.stride(0), N, F_l, part.data_ptr(), st),
+                              "gnm_rowdot_partials")
+                elif not fused:
                     _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True,
                          hfwd=h_in if spec.learn_eps else None, deps_partial=part)
                 if l > 0:

@@ -87,6 +87,11 @@ int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t*
 int gnm_agg_slice_width(int F, int n_max);          /* feature-slice width the kernel will use (0: unsupported) */
 int gnm_agg_num_partials(int F, int n_max, int B);  /* doubles written to deps_partial */
 int gnm_sum_partials(const double* partial, int count, float* out, void* stream);
+/* d eps[l] = sum_v dpooled[v,:] . h[v,:] (graphcnn.py:161) without the gather, for a layer whose aggregation
+ * backward has no other consumer: gnm_rowdot_num_partials() fp64 partials, to be summed like gnm_agg's. */
+int gnm_rowdot_num_partials(void);
+int gnm_rowdot_partials(const float* A, int lda, const float* B, int ldb, long long N, int F, double* partial,
+                        void* stream);
 /* nsets (<= 16) independent sets in one launch: out[k] = sum of partial[k*stride .. k*stride + counts_host[k]) */
 int gnm_sum_partials_multi(const double* partial, long long stride, const int* counts_host, int nsets, float* out,
                            void* stream);
