@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--no-learn-eps", action="store_true")
     ap.add_argument("--no-direct-grads", action="store_true",
                     help="let autograd accumulate parameter gradients instead of writing them into the flat buffer")
+    ap.add_argument("--agg0-cache", action="store_true",
+                    help="take layer 0's parameter-independent A.X from the arena's per-graph cache instead of "
+                         "aggregating the input features inside every step (off: the step does all the work)")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N > 1: BatchNorm over the union batch (20 tiny all-reduces per step, eager launches)")
     ap.add_argument("--torch-loss", action="store_true",
@@ -183,7 +186,8 @@ def main():
     if use_graph:
         from gnm.graphs import CapturedTrainStep
         try:
-            captured = CapturedTrainStep(model, batches[0][0], loss_fn, zero_grad=dp.zero_grad)
+            captured = CapturedTrainStep(model, batches[0][0], loss_fn, zero_grad=dp.zero_grad,
+                                         agg0_cache=args.agg0_cache)
         except Exception as e:                      # capture is an optimisation: fall back to eager launches
             print("hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
             captured = None
@@ -192,13 +196,16 @@ def main():
 
     use_captured = captured is not None
 
+    def feats(bt):          # explicit X = aggregate it in the step; None = arena cache (--agg0-cache)
+        return None if args.agg0_cache else arena.features(bt)
+
     def step(i):
         bt, lab = batches[i]
         if use_captured:
             loss = captured.run(bt, lab, perms[i])
         else:
             dp.zero_grad()
-            c_logit, d_logit = model.forward_batch(bt, perm=perms[i])
+            c_logit, d_logit = model.forward_batch(bt, X=feats(bt), perm=perms[i])
             loss = loss_fn(c_logit, d_logit, lab)
             loss.backward()
         dp.allreduce_gradients()
@@ -251,7 +258,7 @@ def main():
         core.TIMER = core.KernelTimer(("agg_fwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
         for i in range(min(3, nsteps)):
             bt, lab = batches[i]
-            c_logit, d_logit = model.forward_batch(bt, perm=perms[i])
+            c_logit, d_logit = model.forward_batch(bt, X=feats(bt), perm=perms[i])
             loss_fn(c_logit, d_logit, lab).backward()
         torch.cuda.synchronize()
         timer, core.TIMER = core.TIMER, None

@@ -16,6 +16,8 @@ struct GPtrs {
 };
 
 static constexpr int kHeadThreads = 256;
+static constexpr int kHeadCols = 8;                               // columns of one dWp row per gradient block
+static constexpr int kHeadSlices = kHeadThreads / kHeadCols;      // batch slices summed in parallel
 
 // One workgroup per graph b:
 //   csig[b, j]    = sigmoid(g_f[b, j])                                       j < L*H
@@ -54,7 +56,7 @@ __global__ void __launch_bounds__(kHeadThreads) gnm_head_fwd_kernel(const float*
 // Blocks [0, B): per graph b, the gradient wrt the graph summary, laid out like g_f:
 //   dph[b, lH+h] = sum_c dC[b,c] mask[l,b,c] Wp[l][c,h]  +  T[b, lH+h] * cs (1 - cs)        cs = csig[b, lH+h]
 // (second term only when T = dU Wd is given: the discriminator's path through the sigmoid).
-// Blocks [B, B+L): per layer l, the classifier parameter gradients, reduced over the batch in a fixed order:
+// Blocks [B, B + L*C*ceil(H/8)): the classifier parameter gradients, reduced over the batch in a fixed order:
 //   dWp[l][c,h] = sum_b dC[b,c] mask[l,b,c] g_f[b, lH+h] ;  dbp[l][c] = sum_b dC[b,c] mask[l,b,c]
 __global__ void __launch_bounds__(kHeadThreads) gnm_head_bwd_kernel(const float* __restrict__ dC, int lddc,
                                                                     const float* __restrict__ masks,
@@ -82,14 +84,19 @@ __global__ void __launch_bounds__(kHeadThreads) gnm_head_bwd_kernel(const float*
         }
         return;
     }
-    const int l = blockIdx.x - B;
-    const int nOut = C * H;                        // <= kHeadThreads (checked on the host)
-    const int S = kHeadThreads / nOut;             // batch slices summed in parallel, combined in slice order
-    const int o = tid % nOut, s = tid / nOut;
-    const int c = o / H, h = o - c * H;
+    // parameter gradients: one block per (layer, class, group of 8 columns); 32 batch slices per column run in
+    // parallel (the sum over B is a latency chain otherwise) and are combined in slice order through LDS
+    const int hgroups = (H + kHeadCols - 1) / kHeadCols;
+    int q = blockIdx.x - B;
+    const int l = q / (C * hgroups);
+    q -= l * C * hgroups;
+    const int c = q / hgroups, h0 = (q - c * hgroups) * kHeadCols;
+    const int hh = tid % kHeadCols, sl = tid / kHeadCols;          // sl < kHeadSlices
+    const int h = h0 + hh;
     float acc = 0.f, accb = 0.f;
-    if (s < S) {
-        for (int b = s; b < B; b += S) {
+    if (h < H) {
+#pragma unroll 4
+        for (int b = sl; b < B; b += kHeadSlices) {
             const float m = masks ? masks[((size_t)l * B + b) * C + c] : 1.f;
             const float d = dC[(size_t)b * lddc + c] * m;
             acc = fmaf(d, g_f[(size_t)b * ldg + l * H + h], acc);
@@ -99,11 +106,11 @@ __global__ void __launch_bounds__(kHeadThreads) gnm_head_bwd_kernel(const float*
     red[tid] = acc;
     red[kHeadThreads + tid] = accb;
     __syncthreads();
-    if (tid < nOut) {
+    if (tid < kHeadCols && h < H) {
         float a = 0.f, ab = 0.f;
-        for (int k = 0; k < S; ++k) {
-            a += red[k * nOut + tid];
-            ab += red[kHeadThreads + k * nOut + tid];
+        for (int k = 0; k < kHeadSlices; ++k) {
+            a += red[k * kHeadCols + tid];
+            ab += red[kHeadThreads + k * kHeadCols + tid];
         }
         gp.w[l][(size_t)c * H + h] = a;
         if (h == 0) gp.b[l][c] = ab;
@@ -111,7 +118,7 @@ __global__ void __launch_bounds__(kHeadThreads) gnm_head_bwd_kernel(const float*
 }
 
 static bool head_shape_ok(int B, int L, int H, int C) {
-    return B >= 0 && L >= 1 && L <= GNM_MAX_LAYERS && H >= 1 && C >= 1 && C * H <= kHeadThreads && L * C <= 4096;
+    return B >= 0 && L >= 1 && L <= GNM_MAX_LAYERS && H >= 1 && C >= 1 && C <= kHeadThreads && L * C <= 4096;
 }
 
 extern "C" int gnm_head_fwd(const float* g_f, int ldg, int B, int L, int H, int C, const float* const* wp_host,
@@ -146,7 +153,8 @@ extern "C" int gnm_head_bwd(const float* dC, int lddc, const float* masks, const
         gp.w[l] = l < L ? dwp_host[l] : nullptr;
         gp.b[l] = l < L ? dbp_host[l] : nullptr;
     }
-    hipLaunchKernelGGL(gnm_head_bwd_kernel, dim3(B + L), dim3(kHeadThreads), (size_t)2 * kHeadThreads * 4,
+    const int hgroups = (H + kHeadCols - 1) / kHeadCols;
+    hipLaunchKernelGGL(gnm_head_bwd_kernel, dim3(B + L * C * hgroups), dim3(kHeadThreads), (size_t)2 * kHeadThreads * 4,
                        reinterpret_cast<hipStream_t>(stream), dC, lddc, masks, g_f, ldg, csig, ldcs, T, ldt, B, L, H, C,
                        wp, gp, dph, lddph);
     GNM_CHECK_LAUNCH();

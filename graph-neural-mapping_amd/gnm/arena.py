@@ -64,6 +64,8 @@ class GraphArena:
         self.sym = []
         self._dev_tables = None
         self._token = object()
+        self._agg0 = {}
+        self._minus_one = None
 
     def __len__(self):
         return len(self.n)
@@ -162,18 +164,66 @@ class GraphArena:
             b.t_rp_off, b.t_col_off = tb["trp"][gd], tb["tcol"][gd]
         return b
 
-    def features(self, batch):
-        """X_concat (graphcnn.py:195) gathered on the device: [N, F0] fp32."""
+    def _feature_rows(self, batch):
         tb = self._tables()
         if batch.equal_n:
             base = tb["feat"][batch.gids]
-            idx = (base[:, None] + torch.arange(batch.n_max, device=self.device)[None, :]).reshape(-1)
-        else:
-            ns = tb["n"][batch.gids]
-            base = torch.repeat_interleave(tb["feat"][batch.gids], ns)
-            start = torch.repeat_interleave(torch.as_tensor(batch.node_off_host[:-1], device=self.device), ns)
-            idx = base + (torch.arange(batch.N, device=self.device) - start)
-        return self.feat.buf.index_select(0, idx)
+            return (base[:, None] + torch.arange(batch.n_max, device=self.device)[None, :]).reshape(-1)
+        ns = tb["n"][batch.gids]
+        base = torch.repeat_interleave(tb["feat"][batch.gids], ns)
+        start = torch.repeat_interleave(torch.as_tensor(batch.node_off_host[:-1], device=self.device), ns)
+        return base + (torch.arange(batch.N, device=self.device) - start)
+
+    def features(self, batch):
+        """X_concat (graphcnn.py:195) gathered on the device: [N, F0] fp32."""
+        return self.feat.buf.index_select(0, self._feature_rows(batch))
+
+    # layer 0's neighbour aggregation of the INPUT features does not depend on any parameter:
+    #   learn_eps:  pooled_0 = A X [/deg] + (1 + eps_0) X      (graphcnn.py:154-161)  -> cache A X [/deg]
+    #   otherwise:  pooled_0 = (A + I) X [/(deg + 1)]          (graphcnn.py:178-182)  -> cache all of it
+    # so it is computed once per graph (by the same gnm_agg kernel, over the arena's own feature rows) and a
+    # forward only gathers it, like the features themselves.
+    AGG0_CACHE_BYTES = 8 << 30
+
+    def _agg0_store(self, average, self_loop):
+        key = (bool(average), bool(self_loop))
+        store = self._agg0.setdefault(key, {"buf": None, "graphs": 0})
+        G = len(self.n)
+        if store["graphs"] == G:
+            return store["buf"]
+        rows_done = self.feat_off[store["graphs"]]          # rows of the graphs already cached
+        if store["buf"] is None or store["buf"].shape[0] < self.feat.size:
+            nb = torch.zeros((self.feat.buf.shape[0], self.feat.width), dtype=torch.float32, device=self.device)
+            if store["buf"] is not None:
+                nb[:rows_done].copy_(store["buf"][:rows_done])
+            store["buf"] = nb
+        if self._minus_one is None:
+            self._minus_one = torch.full((1,), -1.0, dtype=torch.float32, device=self.device)
+        minus_one = self._minus_one                                   # eps = -1: no self term
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        F0 = self.feat.width
+        for g0 in range(store["graphs"], G, 4096):
+            g1 = min(G, g0 + 4096)
+            bt = self.batch_from_gids(np.arange(g0, g1, dtype=np.int64))
+            r0 = self.feat_off[g0]
+            x = self.feat.buf[r0:r0 + bt.N]                 # feature rows are stored in arena (= this batch's) order
+            y = store["buf"][r0:r0 + bt.N]
+            check(lib.gnm_agg(self.rowptr.buf.data_ptr(), self.col.buf.data_ptr(), bt.rp_off.data_ptr(),
+                              bt.col_off.data_ptr(), self.rowptr.buf.data_ptr(), bt.rp_off.data_ptr(),
+                              bt.node_off.data_ptr(), bt.B, bt.n_max, bt.nnz_max, x.data_ptr(), x.stride(0),
+                              y.data_ptr(), y.stride(0), F0, None if self_loop else minus_one.data_ptr(),
+                              int(bool(average)), int(bool(self_loop)), 0, None, 0, None, st), "gnm_agg")
+        store["graphs"] = G
+        return store["buf"]
+
+    def features_and_agg0(self, batch, average, self_loop):
+        """(X_concat, cached layer-0 aggregate) for the batch; the second is None when the cache would
+        exceed AGG0_CACHE_BYTES (wide one-hot inputs on huge pools)."""
+        idx = self._feature_rows(batch)
+        X = self.feat.buf.index_select(0, idx)
+        if self.feat.buf.numel() * 4 > self.AGG0_CACHE_BYTES:
+            return X, None
+        return X, self._agg0_store(average, self_loop).index_select(0, idx)
 
     # ------------------------------------------------------------------ parity export
     def export_adj_coo(self, batch, self_loops):

@@ -142,9 +142,10 @@ class _LinSave:
     __slots__ = ("x_in", "pro", "z", "scale", "shift", "mean", "rstd", "K", "H", "Ng")
 
 
-def encoder_forward(spec, batch, X, P, training, update_running):
+def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
     """The L GIN layers + readout.  P: dict of parameter/buffer tensors keyed by the
-    reference's state_dict names.  Returns (hidden list, g_f [B, L*H], saved)."""
+    reference's state_dict names.  P0: the arena's cached parameter-independent part of layer 0's
+    aggregation (GraphArena.features_and_agg0) or None.  Returns (hidden list, g_f [B, L*H], saved)."""
     dev = X.device
     N, B = batch.N, batch.B
     L, m = spec.L, spec.m
@@ -157,9 +158,13 @@ def encoder_forward(spec, batch, X, P, training, update_running):
     Ng = sync.global_count(N, dev) if sync is not None else N        # rows of the union batch
     for l in range(L):
         F_l = h.shape[1]
-        pooled = torch.empty((N, F_l), **f32)
         eps_ptr = P["eps"].data_ptr() + 4 * l if spec.learn_eps else None
-        _agg(batch, h, pooled, F_l, eps_ptr, spec, backward=False)        # graphcnn.py:154-161 / 178-182
+        if l == 0 and P0 is not None:
+            # A X [/deg] comes from the arena's cache; only the (1 + eps_0) X self term depends on a parameter
+            pooled = torch.addcmul(P0, h, P["eps"][0:1] + 1.0) if spec.learn_eps else P0
+        else:
+            pooled = torch.empty((N, F_l), **f32)
+            _agg(batch, h, pooled, F_l, eps_ptr, spec, backward=False)    # graphcnn.py:154-161 / 178-182
         x_in, pro, lins = pooled, None, []
         for k in range(m):                                                   # mlp.py:40-49
             if m == 1:
@@ -209,25 +214,25 @@ _ptr_array = _hptr_array
 
 
 class GinInfoMaxFn(torch.autograd.Function):
-    """(X, *params) -> (c_logit [B,C], d_logit [2N,1], g_f [B,L*H])."""
+    """(P0, X, *params) -> (c_logit [B,C], d_logit [2N,1], g_f [B,L*H])."""
 
     @staticmethod
-    def forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, X, *tensors):
+    def forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, P0, X, *tensors):
         if not X.is_cuda:
             raise GnmError("the GIN hot path runs on the GPU only (libgnm_hip.so); got a %s tensor" % X.device)
         ctx.set_materialize_grads(False)
         with _stream_scope():
-            return GinInfoMaxFn._forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, X,
-                                         tensors)
+            return GinInfoMaxFn._forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, P0,
+                                         X, tensors)
 
     @staticmethod
-    def _forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, X, tensors):
+    def _forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, P0, X, tensors):
         P = dict(zip(names, tensors))
         P.update(buffers)
         L = spec.L
         N, B = batch.N, batch.B
         X = X.contiguous()
-        hidden, g_f, saved = encoder_forward(spec, batch, X, P, training, update_running=training)
+        hidden, g_f, saved = encoder_forward(spec, batch, X, P, training, update_running=training, P0=P0)
         H = hidden[0].shape[1]
         # classifier head (graphcnn.py:224-231) and sigmoid(g_f) (:239): one launch (csrc/head.hip)
         wps = [P[f"linears_prediction.{l}.weight"] for l in range(L)]
@@ -248,7 +253,7 @@ class GinInfoMaxFn(torch.autograd.Function):
             else:
                 check(rc, "gnm_head_fwd")
         Wp = None
-        if not fused_head:          # shapes outside the head kernel (C*H > 256): batched matrix products
+        if not fused_head:          # shapes outside the head kernel (C > 256 classes): batched matrix products
             Wp = torch.stack(wps)                                                            # [L,C,H]
             G3 = g_f.view(B, L, H).transpose(0, 1)                                           # [L,B,H] view
             lg = torch.baddbmm(torch.stack(bps).unsqueeze(1), G3, Wp.transpose(1, 2))        # [L,B,C]
@@ -303,7 +308,7 @@ class GinInfoMaxFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         st = _stream()
         grads = {}
-        need_dx = ctx.needs_input_grad[8]
+        need_dx = ctx.needs_input_grad[9]
         sink = spec.grad_sink
 
         def out_like(name, ref):
@@ -549,7 +554,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                                              deps.data_ptr(), st), "gnm_sum_partials_multi")
             if sink is None:
                 grads["eps"] = deps
-        out = [None] * 8 + [dX if need_dx else None]
+        out = [None] * 9 + [dX if need_dx else None]
         for i, name in enumerate(ctx.names):
-            out.append(grads.get(name) if ctx.needs_input_grad[9 + i] else None)
+            out.append(grads.get(name) if ctx.needs_input_grad[10 + i] else None)
         return tuple(out)

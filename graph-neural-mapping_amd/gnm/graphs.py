@@ -17,7 +17,8 @@ from .arena import StaticBatch
 
 
 class CapturedTrainStep:
-    def __init__(self, model, template_batch, loss_fn, zero_grad=None, warmup=3, post_backward=None, preserve=()):
+    def __init__(self, model, template_batch, loss_fn, zero_grad=None, warmup=3, post_backward=None, preserve=(),
+                 agg0_cache=True):
         """loss_fn(c_logit, d_logit, labels) -> scalar loss.  zero_grad(): clears the
         gradient buffers (default: model.zero_grad(set_to_none=False)).  post_backward(): extra
         capturable work recorded after backward (e.g. a fused optimizer step).  The warm-up passes
@@ -25,6 +26,7 @@ class CapturedTrainStep:
         `preserve` (optimizer state) are put back afterwards, so construction has no side effect."""
         self.model = model
         self._post = post_backward
+        self._agg0_cache = agg0_cache      # False: aggregate the input features inside the step (bench.py)
         keep = [t for t in model.state_dict().values()] + list(preserve)
         snapshot = [t.clone() for t in keep]
         dev = template_batch.node_off.device
@@ -55,7 +57,9 @@ class CapturedTrainStep:
 
     def _step(self):
         self._zero()
-        c_logit, d_logit = self.model.forward_batch(self.static.batch, perm=self.perm)
+        bt = self.static.batch
+        X = None if self._agg0_cache else bt.arena.features(bt)
+        c_logit, d_logit = self.model.forward_batch(bt, X=X, perm=self.perm)
         loss = self._loss_fn(c_logit, d_logit, self.labels)
         loss.backward()
         if self._post is not None:

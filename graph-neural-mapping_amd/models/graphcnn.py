@@ -85,19 +85,21 @@ class GIN_InfoMaxReg(nn.Module):
             pl = self._plist = (names, tensors, dict(self.named_buffers()))
         return pl
 
-    def _run(self, batch, X, perm, want_disc):
+    def _run(self, batch, X, perm, want_disc, P0=None):
         names, tensors, buffers = self._param_lists()
         return GinInfoMaxFn.apply(self._spec, batch, perm, names, buffers, self.training, float(self.final_dropout),
-                                  want_disc, X, *tensors)
+                                  want_disc, P0, X, *tensors)
 
     def forward_batch(self, batch, X=None, perm=None, latent=False):
         """forward() for an already assembled gnm.arena.Batch (what bench.py and the
         data-parallel driver call: no per-graph Python work)."""
         if perm is None:
             perm = np.random.permutation(batch.B)                             # graphcnn.py:199
+        P0 = None
         if X is None:
-            X = batch.arena.features(batch)
-        c_logit, d_logit, g_f = self._run(batch, X, perm, want_disc=True)
+            # layer 0's A X [/deg] does not depend on the parameters: gathered from the arena's per-graph cache
+            X, P0 = batch.arena.features_and_agg0(batch, self._spec.n_avg, not self._spec.learn_eps)
+        c_logit, d_logit, g_f = self._run(batch, X, perm, want_disc=True, P0=P0)
         if latent:
             return g_f.detach().cpu().numpy()                                  # graphcnn.py:248-249
         return c_logit, d_logit

@@ -177,7 +177,7 @@ int gnm_disc_score_bwd(const float* const* hptrs_host, int ldh, int L, int H, co
  *                csig = sigmoid(g_f)                                                           (:239, may be NULL)
  * gnm_head_bwd:  dph [B, L*H] = d loss / d g_f = classifier path + T * csig * (1 - csig) (T = dU Wd or NULL);
  *                dwp_host / dbp_host: HOST arrays of L device pointers receiving the classifier gradients.
- * GNM_ERR_UNSUPPORTED when C*H > 256 or L > 16 (the caller then uses plain matrix products). */
+ * GNM_ERR_UNSUPPORTED when C > 256 or L > 16 (the caller then uses plain matrix products). */
 int gnm_head_fwd(const float* g_f, int ldg, int B, int L, int H, int C, const float* const* wp_host,
                  const float* const* bp_host, const float* masks, float* c_logit, int ldc, float* csig, int ldcs,
                  void* stream);

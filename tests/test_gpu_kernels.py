@@ -443,7 +443,8 @@ def test_discriminator_scores_vs_literal_bilinear(B, n, L, H):
 
 # ------------------------------------------------------------------ graph-level head
 @pytest.mark.parametrize("B,L,H,C,p,with_T", [(3, 5, 64, 2, 0.5, True), (4, 3, 32, 2, 0.0, True), (1, 2, 32, 3, 0.3, False),
-                                              (257, 5, 128, 2, 0.5, True), (5, 1, 20, 7, 0.0, False)])
+                                              (257, 5, 128, 2, 0.5, True), (5, 1, 20, 7, 0.0, False),
+                                              (1024, 5, 64, 2, 0.5, True), (9, 2, 200, 3, 0.0, True)])
 def test_head_fwd_bwd_vs_numpy(B, L, H, C, p, with_T):
     """gnm_head_fwd / gnm_head_bwd against the per-layer restatement of graphcnn.py:224-231,239 in fp64."""
     import ctypes as CT
@@ -496,13 +497,14 @@ def test_head_fwd_bwd_vs_numpy(B, L, H, C, p, with_T):
 def test_head_unsupported_shape_is_reported():
     import ctypes as CT
     from gnm._cabi import lib
-    g = torch.zeros((2, 2 * 200), device=DEV)
-    w = [torch.zeros((2, 200), device=DEV) for _ in range(2)]
-    b = [torch.zeros(2, device=DEV) for _ in range(2)]
-    wp = (CT.c_void_p * 2)(*[x.data_ptr() for x in w])
-    bp = (CT.c_void_p * 2)(*[x.data_ptr() for x in b])
-    out = torch.zeros((2, 2), device=DEV)
-    assert lib.gnm_head_fwd(g.data_ptr(), 400, 2, 2, 200, 2, wp, bp, None, out.data_ptr(), 2, None, 0, _stream()) == -2
+    L, H, Cn = 2, 8, 300                      # more classes than the head kernel's 256 threads
+    g = torch.zeros((2, L * H), device=DEV)
+    w = [torch.zeros((Cn, H), device=DEV) for _ in range(L)]
+    b = [torch.zeros(Cn, device=DEV) for _ in range(L)]
+    wp = (CT.c_void_p * L)(*[x.data_ptr() for x in w])
+    bp = (CT.c_void_p * L)(*[x.data_ptr() for x in b])
+    out = torch.zeros((2, Cn), device=DEV)
+    assert lib.gnm_head_fwd(g.data_ptr(), L * H, 2, L, H, Cn, wp, bp, None, out.data_ptr(), Cn, None, 0, _stream()) == -2
 
 
 # ------------------------------------------------------------------ full-size properties

@@ -453,3 +453,42 @@ def test_ragged_batch_is_rejected_like_the_reference():
     model = GIN_InfoMaxReg(2, 2, 7, 32, 2, 0.0, True, "sum", "sum", dev).to(dev)
     with pytest.raises(RuntimeError):
         model(graphs)
+
+
+@pytest.mark.parametrize("learn_eps,npool", [(True, "sum"), (True, "average"), (False, "sum"), (False, "average")])
+def test_layer0_aggregate_cache_equals_direct_aggregation(learn_eps, npool):
+    """GraphArena.features_and_agg0: layer 0's parameter-independent A X [/deg] comes from a per-graph cache
+    (built by the same gnm_agg kernel); passing X explicitly runs the aggregation in the step.  Same results, also
+    after the arena has grown past the cached prefix, and eps_0 still gets its gradient."""
+    from gnm import synth
+    from models.graphcnn import GIN_InfoMaxReg
+    dev = torch.device(DEV)
+    pool = synth.make_pool("dense_fc", 10, n=50, t=64, f0=7)
+    torch.manual_seed(1)
+    m = GIN_InfoMaxReg(3, 2, 7, 32, 2, 0.0, learn_eps, "sum", npool, dev).to(dev).train()
+    with torch.no_grad():
+        m.eps.copy_(torch.tensor([0.3, -0.2, 0.1]))
+    ar = m.arena()
+    gids = [ar.add(g) for g in pool[:6]]
+    for round_ in range(2):
+        if round_ == 1:                                   # grow the arena: the cache must extend, not restart
+            gids = gids[2:] + [ar.add(g) for g in pool[6:]]
+        bt = ar.batch_from_gids(np.array(gids, dtype=np.int64))
+        perm = np.arange(len(gids))[::-1].copy()
+        outs = []
+        for explicit in (False, True):
+            m.zero_grad()
+            X = ar.features(bt) if explicit else None
+            c, d = m.forward_batch(bt, X=X, perm=perm)
+            (c.square().sum() + d.square().mean()).backward()
+            outs.append((c.detach().cpu().numpy(), d.detach().cpu().numpy(),
+                         {k: p.grad.detach().cpu().numpy().copy() for k, p in m.named_parameters() if p.grad is not None}))
+        assert_close(outs[0][0], outs[1][0], rtol=RTOL, what="c_logit")
+        assert_close(outs[0][1], outs[1][1], rtol=RTOL, what="d_logit")
+        gmax = max(np.abs(v).max() for v in outs[1][2].values())
+        for k, v in outs[1][2].items():
+            assert_close(outs[0][2][k], v, rtol=5e-5, what=k, floor=2e-2 * gmax)
+        if learn_eps:
+            assert abs(outs[0][2]["eps"][0]) > 0
+    X, P0 = ar.features_and_agg0(bt, npool == "average", not learn_eps)
+    assert P0 is not None and P0.shape == X.shape
