@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._cabi import check, lib
+from ._cabi import GnmError, check, lib
 
 
 class _Growable:
@@ -186,6 +186,8 @@ class GraphArena:
     AGG0_CACHE_BYTES = 8 << 30
 
     def _agg0_store(self, average, self_loop):
+        if self.device.type != "cuda":
+            raise GnmError("the GIN hot path runs on the GPU only (libgnm_hip.so); the arena is on %s" % self.device)
         key = (bool(average), bool(self_loop))
         store = self._agg0.setdefault(key, {"buf": None, "graphs": 0})
         G = len(self.n)
