@@ -806,7 +806,7 @@ __global__ void __launch_bounds__(256) gnm_reduce_partials_kernel(const float* _
 // The dZ tile lives only in the wave's LDS staging image: dgrad reads it row-wise
 // (ds_read_b128 A fragments), wgrad column-wise (ds_read_b32, lane = column).  f(X) operands
 // come straight from global memory (128 B per half-wave), all loads of a tile are issued
-// before its MFMAs.  K, H in {32, 64} (accumulators: 32*K/32 + 16*(H/32)*(K/32) registers).
+// before its MFMAs.  K, H in {32, 64} (accumulators: 32*K/32 + 16*(H/32)*(K/32) registers), or K < 32 (NARROW).
 // ------------------------------------------------------------------------------
 struct LbArgs {
     const float* G; const float* Z; const float* X; const float* W;
@@ -822,8 +822,11 @@ struct LbArgs {
     int pro_relu;
 };
 
-template <int KT, int HT, bool STATS>
+// NARROW: K < 32 (the first Linear of layer 0, K = F0): one zero-padded 32-column tile, guarded scalar
+// accesses to X / W / dX, which are small next to the [N,H] streams G and Z.
+template <int KT, int HT, bool STATS, bool NARROW = false>
 __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbArgs p) {   // 2 waves/SIMD: <= 256 registers
+    static_assert(!NARROW || (KT == 1 && !STATS), "narrow K: one tile, no lower BatchNorm");
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
     constexpr int H4 = HP / 4;                    // float4 per dZ row
@@ -841,7 +844,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     float* Xs = Xs_all + wave * 32 * XS;
     for (int idx = tid; idx < HP * KP; idx += 256) {
         const int hh = idx / KP, k = idx - hh * KP;
-        Wt[idx] = p.W[(size_t)hh * p.ldw + k];
+        Wt[idx] = (!NARROW || k < p.K) ? p.W[(size_t)hh * p.ldw + k] : 0.f;
     }
     __syncthreads();
 
@@ -854,8 +857,9 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     float psc[KT], psh[KT];
 #pragma unroll
     for (int b = 0; b < KT; ++b) {
-        psc[b] = p.pro_scale ? p.pro_scale[32 * b + i] : 1.f;
-        psh[b] = p.pro_scale ? p.pro_shift[32 * b + i] : 0.f;
+        const bool kin = !NARROW || 32 * b + i < p.K;
+        psc[b] = (p.pro_scale && kin) ? p.pro_scale[32 * b + i] : 1.f;
+        psh[b] = (p.pro_scale && kin) ? p.pro_shift[32 * b + i] : 0.f;
     }
     f32x16 wacc[HT][KT];                          // dW accumulators
 #pragma unroll
@@ -907,7 +911,8 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
         for (int s = 0; s < 16; ++s) {
             const int grow = min(r0 + 2 * s + h, nlast);
 #pragma unroll
-            for (int b = 0; b < KT; ++b) xv[s][b] = p.X[(size_t)grow * p.ldx + 32 * b + i];
+            for (int b = 0; b < KT; ++b)
+                xv[s][b] = (!NARROW || 32 * b + i < p.K) ? p.X[(size_t)grow * p.ldx + 32 * b + i] : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- dX = dZ W ------------------------------------------------------------------
@@ -943,6 +948,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
                 if (p.pro_scale) {
                     x = x * psc[b] + psh[b];
                     if (p.pro_relu) x = fmaxf(x, 0.f);
+                    if (NARROW && !(32 * b + i < p.K)) x = 0.f;      // padding columns stay zero
                 }
                 xv[s][b] = x;
             }
@@ -998,6 +1004,11 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
                         ss2.z += g.z * ((z.z - lmu.z) * lrs.z); ss2.w += g.w * ((z.w - lmu.w) * lrs.w);
                     }
                 }
+                }
+            } else if constexpr (NARROW) {
+                for (int idx = lane; idx < 32 * p.K; idx += 64) {
+                    const int row = idx / p.K, col = idx - row * p.K;
+                    if (r0 + row < p.N) p.dA[(size_t)(r0 + row) * p.lda + col] = Xs[row * XS + col];
                 }
             } else {
 #pragma unroll
@@ -1066,7 +1077,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
         float sum = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) sum += dump[(size_t)w * HT * KT * TILE + idx];
-        out[(size_t)row * p.K + col] = sum;
+        if (!NARROW || col < p.K) out[(size_t)row * p.K + col] = sum;
     }
     for (int idx = tid; idx < HT * 32; idx += 256) {
         const int a = idx >> 5, ii = idx & 31;
@@ -1077,7 +1088,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     }
 }
 
-template <int KT, int HT, bool STATS>
+template <int KT, int HT, bool STATS, bool NARROW = false>
 static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
@@ -1086,11 +1097,11 @@ static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     if (dump > lds) lds = dump;
     static bool configured = false;
     if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_linear_bwd_fused_kernel<KT, HT, STATS>),
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         configured = true;
     }
-    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT, STATS>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
@@ -1114,10 +1125,11 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
                                     const float* s_scale, const float* s_shift, const float* s_mean,
                                     const float* s_rstd, double* s_partial, void* stream) {
     if (N <= 0) return GNM_ERR_UNSUPPORTED;
-    if ((K != 32 && K != 64) || (H != 32 && H != 64)) return GNM_ERR_UNSUPPORTED;
-    if ((ldg & 3) || (ldz & 3) || (dA && (lda & 3)) || getenv("GNM_LIN_GENERIC")) return GNM_ERR_UNSUPPORTED;
+    const bool narrow = K >= 1 && K < 32 && !sZ;            // zero-padded single K tile, scalar X / dX accesses
+    if ((K != 32 && K != 64 && !narrow) || (H != 32 && H != 64)) return GNM_ERR_UNSUPPORTED;
+    if ((ldg & 3) || (ldz & 3) || (dA && !narrow && (lda & 3)) || getenv("GNM_LIN_GENERIC")) return GNM_ERR_UNSUPPORTED;
     const uintptr_t al = reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Z) |
-                         reinterpret_cast<uintptr_t>(dA) | reinterpret_cast<uintptr_t>(mean) |
+                         (narrow ? 0 : reinterpret_cast<uintptr_t>(dA)) | reinterpret_cast<uintptr_t>(mean) |
                          reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(cA) |
                          reinterpret_cast<uintptr_t>(m1) | reinterpret_cast<uintptr_t>(m2);
     if (al & 15) return GNM_ERR_UNSUPPORTED;
@@ -1137,7 +1149,9 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = gnm_linear_bwd_grid(N);
     int rc = GNM_ERR_UNSUPPORTED;
-    const int KT = K / 32, HT = H / 32;
+    const int KT = narrow ? 0 : K / 32, HT = H / 32;
+    if (narrow && HT == 1) rc = launch_lb<1, 1, false, true>(a, grid, s);
+    if (narrow && HT == 2) rc = launch_lb<1, 2, false, true>(a, grid, s);
     if (KT == 1 && HT == 1) rc = sZ ? launch_lb<1, 1, true>(a, grid, s) : launch_lb<1, 1, false>(a, grid, s);
     if (KT == 2 && HT == 1) rc = sZ ? launch_lb<2, 1, true>(a, grid, s) : launch_lb<2, 1, false>(a, grid, s);
     if (KT == 1 && HT == 2) rc = sZ ? launch_lb<1, 2, true>(a, grid, s) : launch_lb<1, 2, false>(a, grid, s);

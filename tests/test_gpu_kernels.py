@@ -246,7 +246,8 @@ def test_linear_forward_stats_and_grads(N, K, H, pro):
     assert_close(db.cpu().numpy(), dZ.astype(np.float64).sum(0), rtol=TOL, what="bias grad")
 
 
-@pytest.mark.parametrize("N,K,H", [(1000, 64, 64), (33, 64, 64), (4099, 32, 64), (257, 64, 32), (700, 32, 32)])
+@pytest.mark.parametrize("N,K,H", [(1000, 64, 64), (33, 64, 64), (4099, 32, 64), (257, 64, 32), (700, 32, 32),
+                                   (1000, 7, 64), (97, 5, 32), (4099, 31, 64), (40, 1, 64)])   # K < 32: narrow variant
 @pytest.mark.parametrize("pro,want_dx", [(True, True), (False, True), (True, False)])
 def test_linear_backward_fused(N, K, H, pro, want_dx):
     """gnm_linear_bwd_fused = BatchNorm-backward apply + dX + dW + db in one pass, vs the
@@ -286,9 +287,16 @@ def test_linear_backward_fused(N, K, H, pro, want_dx):
     # ineligible shapes are refused, not mis-computed
     assert lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Zd.data_ptr(), H, md.data_ptr(), rd.data_ptr(), cd.data_ptr(),
                                     m1d.data_ptr(), m2d.data_ptr(), Xd.data_ptr(), K, None, None, 0, Wd.data_ptr(), K,
-                                    None, K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, 7, H, None, 0, None,
+                                    None, K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, 40, H, None, 0, None,
                                     None, None, None, None, _stream()) == -2
-    if want_dx:
+    if want_dx and K < 32:
+        # the narrow variant has no lower-BatchNorm epilogue (an input layer has nothing below it)
+        assert lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Zd.data_ptr(), H, md.data_ptr(), rd.data_ptr(),
+                                        cd.data_ptr(), m1d.data_ptr(), m2d.data_ptr(), Xd.data_ptr(), K, None, None, 0,
+                                        Wd.data_ptr(), K, dA.data_ptr(), K, dW.data_ptr(), K, db.data_ptr(),
+                                        ws.data_ptr(), N, K, H, Gd.data_ptr(), H, md.data_ptr(), md.data_ptr(),
+                                        md.data_ptr(), md.data_ptr(), ws.data_ptr(), _stream()) == -2
+    if want_dx and K >= 32:
         # variant that also applies the ReLU mask of the BatchNorm+ReLU feeding this Linear to dX and
         # reduces that BatchNorm's backward sums (what gnm_bn_relu_bwd_stats would do)
         Zlo = (rng.standard_normal((N, K)) + 0.2).astype(np.float32)
