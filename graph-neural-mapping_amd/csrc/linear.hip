@@ -414,7 +414,8 @@ static int launch_lin(const LinArgs& a, int grid, hipStream_t s) {
 extern "C" int gnm_linear_grid(int N) {
     const int ntiles = (N + 31) / 32;
     int g = (ntiles + 3) / 4;
-    if (g > 768) g = 768;
+    static const int cap = getenv("GNM_LIN_GRID") ? atoi(getenv("GNM_LIN_GRID")) : 768;   // tuning knob
+    if (g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
 
@@ -1108,7 +1109,8 @@ static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
 
 extern "C" int gnm_linear_bwd_grid(int N) {
     int g = ((N + 31) / 32 + 3) / 4;
-    if (g > 512) g = 512;
+    static const int cap = getenv("GNM_LINBWD_GRID") ? atoi(getenv("GNM_LINBWD_GRID")) : 512;   // tuning knob
+    if (g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
 extern "C" long long gnm_linear_bwd_workspace_floats(int N, int H, int K) {
