@@ -303,6 +303,8 @@ def main():
                 tp = os.path.join(ROOT, "profiles", "agg16_traffic.json")
                 if os.path.exists(tp) and H == 64 and n == 400 and default_cfg:
                     tj = json.load(open(tp))      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_agg.sh)
+                    if meta.get("fused_bnrelu"):  # the launches timed carried the BatchNorm+ReLU+readout prologue
+                        tj = tj["fused_bnrelu"]
                     # counted on a 1024-graph launch; one workgroup per graph, so it is linear in the graph count
                     traffic, traffic_src = tj["hbm_bytes_per_launch"] * meta["B"] / 1024.0, tj["source"]
                 roof = {"bound": "hbm", "kernel": "gnm_agg16_kernel (forward, F=%d)" % H, "achieved": ach,
@@ -311,6 +313,12 @@ def main():
                         "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": bytes_launch, "mean_launch_ms": ms, "launches_timed": c,
                         "graph_layers_per_s": meta["B"] / (ms * 1e-3)}
+                if meta.get("fused_bnrelu"):
+                    # the timed launches also apply the previous layer's BatchNorm+ReLU, write that activation
+                    # (4nF bytes per graph, not part of SURVEY 8(d)'s canonical aggregation bytes) and its readout
+                    extra = 4.0 * n * H * meta["B"]
+                    roof["kernel"] = "gnm_agg16_kernel (forward, F=%d, with fused BatchNorm+ReLU+readout prologue)" % H
+                    roof["frac_incl_fused_activation_write"] = (bytes_launch + extra) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             key = "lin_fwd_K%d_H%d" % (H, H)
             if key in summ:
                 c, ms, meta = summ[key]

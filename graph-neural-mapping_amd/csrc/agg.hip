@@ -59,6 +59,11 @@ struct AggArgs {
     int ldsz, ld_dpool, ld_U, s_avg, n_batch;
     int ids_in_lds;            // narrow slices: the graph's column ids are staged in LDS (max_nnz given)
     int debug;                 // tuning only (GNM_AGG16_DEBUG): 1 no id loads, 2 no epilogue/store, 4 no combine
+    // forward prologue (agg16 only): the input is Z of the previous layer's last Linear; the tile load applies that
+    // layer's outer BatchNorm + ReLU, writes the activation h (p_hout) and its graph readout (p_gf) on the way
+    const float* p_scale; const float* p_shift;
+    float* p_hout; float* p_gf;
+    int p_ldh, p_ldgf, p_gf_avg;
 };
 
 template <int S>
@@ -436,7 +441,52 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     constexpr int UNR = 4;
     const bool fast = vec_in && (col0 + FS <= p.F) && (!p.deps_partial || vec_h);
     int base = tid;
-    if (fast) {
+    // forward prologue (non-STATS launches of gnm_agg_fwd_bnrelu only; nthreads is a multiple of 16, so a
+    // thread keeps the column chunk tid & 15 for all its rows)
+    const bool pro = !STATS && p.p_scale != nullptr;
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pro) {
+        psc = *reinterpret_cast<const float4*>(p.p_scale + 4 * (tid & 15));
+        psh = *reinterpret_cast<const float4*>(p.p_shift + 4 * (tid & 15));
+        auto emit = [&](int i, float4 w) {
+            w.x = fmaxf(w.x * psc.x + psh.x, 0.f); w.y = fmaxf(w.y * psc.y + psh.y, 0.f);
+            w.z = fmaxf(w.z * psc.z + psh.z, 0.f); w.w = fmaxf(w.w * psc.w + psh.w, 0.f);
+            *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + (i >> 4)) * p.p_ldh + 4 * (i & 15)) = w;
+            csum.x += w.x; csum.y += w.y; csum.z += w.z; csum.w += w.w;
+            tile[i] = w;
+        };
+        for (; base + (UNR - 1) * nthreads < total; base += nthreads * UNR) {     // UNR x 16 B per thread in flight
+            float4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = base + u * nthreads;
+                v[u] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + (i >> 4)) * p.ldx + 4 * (i & 15));
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) emit(base + u * nthreads, v[u]);
+        }
+        {
+            float4 v[UNR];
+            int cnt = 0;
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = base + u * nthreads;
+                if (i < total) {
+                    v[u] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + (i >> 4)) * p.ldx + 4 * (i & 15));
+                    cnt = u + 1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (u < cnt) emit(base + u * nthreads, v[u]);
+            base = total;
+        }
+        // readout partials: [nthreads] float4 behind the row offsets (the 64 threads of a column chunk)
+        float4* rsum = reinterpret_cast<float4*>(smem + (((size_t)(n + 1) * (FS * 4) + (size_t)(n + 2) * 4 + 15) & ~(size_t)15));
+        rsum[tid] = csum;
+    }
+    if (fast && !pro) {
         // branch-free main part: UNR x 16 B (+ UNR x 16 B of hfwd) per thread in flight
         for (; base + (UNR - 1) * nthreads < total; base += nthreads * UNR) {
             float4 v[UNR], hh[UNR];
@@ -506,6 +556,17 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     }
     if (tid < LPR) tile[n * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    if (pro && p.p_gf && tid < LPR) {
+        // graph readout of the activation just formed (graphcnn.py:229), partials combined in thread order
+        const float4* rsum = reinterpret_cast<const float4*>(smem + (((size_t)(n + 1) * (FS * 4) + (size_t)(n + 2) * 4 + 15) & ~(size_t)15));
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = tid; k < nthreads; k += LPR) acc4(t, rsum[k]);
+        if (p.p_gf_avg) {
+            const float inv = 1.f / (float)n;
+            t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+        }
+        *reinterpret_cast<float4*>(p.p_gf + (size_t)b * p.p_ldgf + 4 * tid) = t;
+    }
 
     // ---- phase B ---------------------------------------------------------------
     const int lane = tid & 63;
@@ -735,7 +796,8 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
 }
 
 static int launch_agg16(const AggArgs& a, int B, int n_max, hipStream_t stream) {
-    const size_t lds = (size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 16;
+    size_t lds = (size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 16;
+    if (a.p_scale) lds += 16 + (size_t)1024 * 16;     // forward prologue: readout partials of up to 1024 threads
     static bool configured = false;
     if (!configured) {
         GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg16_kernel<false>),
@@ -868,6 +930,37 @@ extern "C" int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, con
     a.s_dpool = dpool; a.s_dsc1 = dsc1; a.s_U = U; a.s_inv_perm = inv_perm; a.s_s2sum = s2sum;
     a.s_partial = s_partial; a.ldsz = ldsz; a.ld_dpool = ld_dpool; a.ld_U = ld_U; a.s_avg = graph_avg;
     a.n_batch = B;
+    return launch_agg16(a, B, n_max, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Forward aggregation of layer l+1 whose tile load is layer l's outer BatchNorm + ReLU + graph readout
+// (graphcnn.py:163-166, 229 folded into :154-161): x is Z of layer l's last Linear; hout receives
+// h_l = relu(Z * scale + shift), gf[b, :] its sum (mean) over graph b's nodes, y the aggregation of h_l.
+// Only the 64-wide single-slice LDS shape; GNM_ERR_UNSUPPORTED otherwise (caller: gnm_bn_relu_readout + gnm_agg).
+extern "C" int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
+                                  const int64_t* b_col_off, const int32_t* node_off, int B, int n_max, int nnz_max,
+                                  const float* z, int ldz, const float* scale, const float* shift, float* hout,
+                                  int ldh, float* gf, int ldgf, int graph_avg, float* y, int ldy, int F,
+                                  const float* eps, int average, int self_loop, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (F != 64 || gnm_agg_slice_width(F, n_max) != 64 || !y || !z || !scale || !shift || !hout)
+        return GNM_ERR_UNSUPPORTED;
+    if ((size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 32 + (size_t)1024 * 16 > (size_t)kLdsBudget - 1024)
+        return GNM_ERR_UNSUPPORTED;
+    if ((ldz & 3) || (ldh & 3) || (ldy & 3) || (gf && (ldgf & 3))) return GNM_ERR_UNSUPPORTED;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(scale) |
+                         reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(hout) |
+                         reinterpret_cast<uintptr_t>(gf) | reinterpret_cast<uintptr_t>(y);
+    if (al & 15) return GNM_ERR_UNSUPPORTED;
+    AggArgs a = g_stats_none();
+    a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
+    a.deg_rowptr = rowptr; a.b_deg_off = b_rp_off;
+    a.node_off = node_off; a.x = z; a.y = y; a.eps = eps;
+    a.ldx = ldz; a.ldy = ldy; a.F = F; a.nslices = 1;
+    a.average = average; a.self_loop = self_loop; a.backward = 0;
+    (void)nnz_max;
+    a.p_scale = scale; a.p_shift = shift; a.p_hout = hout; a.p_gf = gf; a.p_ldh = ldh; a.p_ldgf = ldgf;
+    a.p_gf_avg = graph_avg;
     return launch_agg16(a, B, n_max, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -21,6 +21,8 @@ SIGNATURES = {
     "gnm_agg": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p]),
     "gnm_agg_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p, _i, _p,
                                _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
+    "gnm_agg_fwd_bnrelu": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _p, _i, _i, _p, _i, _i, _p, _i,
+                                _i, _p]),
     "gnm_agg_slice_width": (_i, [_i, _i]),
     "gnm_agg_num_partials": (_i, [_i, _i, _i]),
     "gnm_sum_partials": (_i, [_p, _i, _p, _p]),

@@ -156,6 +156,15 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
     h = X
     sync = spec.sync_bn if training else None
     Ng = sync.global_count(N, dev) if sync is not None else N        # rows of the union batch
+    a = batch.arena
+    pending = None      # (z, scale, shift, hout, gslice) of the previous layer: its BatchNorm+ReLU+readout not yet run
+
+    def readout(z, scale, shift, hout, gslice):
+        check(lib.gnm_bn_relu_readout(z.data_ptr(), z.stride(0), scale.data_ptr(), shift.data_ptr(),
+                                      hout.data_ptr(), hout.stride(0), batch.node_off.data_ptr(), B, H, 1,
+                                      gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), _stream()),
+              "gnm_bn_relu_readout")                                          # graphcnn.py:163-166, 228-229
+
     for l in range(L):
         F_l = h.shape[1]
         eps_ptr = P["eps"].data_ptr() + 4 * l if spec.learn_eps else None
@@ -164,7 +173,25 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
             pooled = torch.addcmul(P0, h, P["eps"][0:1] + 1.0) if spec.learn_eps else P0
         else:
             pooled = torch.empty((N, F_l), **f32)
-            _agg(batch, h, pooled, F_l, eps_ptr, spec, backward=False)    # graphcnn.py:154-161 / 178-182
+            fused = False
+            if pending is not None:
+                # the previous layer's BatchNorm + ReLU + readout ride on this aggregation's tile load
+                z, scale, shift, hout, gslice = pending
+                with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1):
+                    rc = lib.gnm_agg_fwd_bnrelu(
+                        a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
+                        batch.col_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max,
+                        z.data_ptr(), z.stride(0), scale.data_ptr(), shift.data_ptr(), hout.data_ptr(),
+                        hout.stride(0), gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), pooled.data_ptr(),
+                        pooled.stride(0), F_l, eps_ptr, int(spec.n_avg), int(not spec.learn_eps), _stream())
+                if rc == -2:
+                    readout(*pending)
+                else:
+                    check(rc, "gnm_agg_fwd_bnrelu")
+                    fused = True
+                pending = None
+            if not fused:
+                _agg(batch, h, pooled, F_l, eps_ptr, spec, backward=False)    # graphcnn.py:154-161 / 178-182
         x_in, pro, lins = pooled, None, []
         for k in range(m):                                                   # mlp.py:40-49
             if m == 1:
@@ -195,10 +222,10 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
             x_in, pro = z, (sv.scale, sv.shift)
         hout = torch.empty((N, H), **f32)
         gslice = g_f[:, l * H:(l + 1) * H]
-        check(lib.gnm_bn_relu_readout(x_in.data_ptr(), x_in.stride(0), pro[0].data_ptr(), pro[1].data_ptr(),
-                                      hout.data_ptr(), hout.stride(0), batch.node_off.data_ptr(), B, H, 1,
-                                      gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), _stream()),
-              "gnm_bn_relu_readout")                                          # graphcnn.py:163-166, 228-229
+        if l < L - 1:
+            pending = (x_in, pro[0], pro[1], hout, gslice)      # deferred into the next layer's aggregation
+        else:
+            readout(x_in, pro[0], pro[1], hout, gslice)
         saved.append((h, pooled, lins))
         hidden.append(hout)
         h = hout

@@ -84,6 +84,16 @@ int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t*
                       const float* s_scale, const float* s_shift, const float* s_mean, const float* s_rstd,
                       const float* dpool, int ld_dpool, int graph_avg, const float* dsc1, const float* U, int ld_U,
                       const int32_t* inv_perm, const float* s2sum, double* s_partial, void* stream);
+/* gnm_agg of layer l+1 whose tile load IS layer l's outer BatchNorm + ReLU + graph readout
+ * (graphcnn.py:163-166 and :229 folded into :154-161): z = output of layer l's last Linear, hout <- h_l =
+ * relu(z*scale+shift), gf[b,:] <- sum (mean when graph_avg) of h_l over graph b (gf may be NULL), y <- the
+ * aggregation of h_l.  64-wide single-slice shape only: GNM_ERR_UNSUPPORTED otherwise (then gnm_bn_relu_readout
+ * followed by gnm_agg). */
+int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
+                       const int32_t* node_off, int B, int n_max, int nnz_max, const float* z, int ldz,
+                       const float* scale, const float* shift, float* hout, int ldh, float* gf, int ldgf,
+                       int graph_avg, float* y, int ldy, int F, const float* eps, int average, int self_loop,
+                       void* stream);
 int gnm_agg_slice_width(int F, int n_max);          /* feature-slice width the kernel will use (0: unsupported) */
 int gnm_agg_num_partials(int F, int n_max, int B);  /* doubles written to deps_partial */
 int gnm_sum_partials(const double* partial, int count, float* out, void* stream);

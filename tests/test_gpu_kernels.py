@@ -449,6 +449,71 @@ def test_discriminator_scores_vs_literal_bilinear(B, n, L, H):
     assert_close(dU.cpu().numpy(), dU_ref, rtol=TOL, what="dU", floor=1e-3 * np.abs(dU_ref).max())
 
 
+@pytest.mark.parametrize("sizes,density", [([40, 40, 40], 0.3), ([37, 5, 64, 1, 23], 0.4), ([400, 400, 400], 0.3),
+                                           ([50, 50], 0.0)])
+@pytest.mark.parametrize("average,learn_eps,graph_avg", [(0, 1, 0), (1, 1, 1), (0, 0, 1), (1, 0, 0)])
+def test_agg_forward_with_fused_bn_relu_readout(sizes, density, average, learn_eps, graph_avg):
+    """gnm_agg_fwd_bnrelu (previous layer's BatchNorm + ReLU + readout on the aggregation's tile load) vs the fp64
+    restatement of graphcnn.py:163-166, 229, 154-161 / 178-182."""
+    from gnm._cabi import check, lib
+    from gnm.arena import GraphArena
+    rng = np.random.default_rng(len(sizes) * 1000 + sizes[0])
+    graphs = random_graphs(rng, sizes, density, True)
+    ar = GraphArena(DEV)
+    batch = ar.batch(graphs)
+    A = dense_adj(graphs)
+    N, F, B = batch.N, 64, batch.B
+    z = rng.standard_normal((N, F)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, F).astype(np.float32)
+    sh = (rng.standard_normal(F) * 0.3).astype(np.float32)
+    eps = 0.37
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    zd, scd, shd, epsd = t(z), t(sc), t(sh), torch.tensor([eps], device=DEV)
+    hout = torch.full((N, F), float("nan"), device=DEV)
+    gf = torch.full((B, 3 * F), float("nan"), device=DEV)          # the readout lands in a column window of g_f
+    y = torch.full((N, F), float("nan"), device=DEV)
+    gwin = gf[:, F:2 * F]
+    check(lib.gnm_agg_fwd_bnrelu(ar.rowptr.buf.data_ptr(), ar.col.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                 batch.col_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max,
+                                 zd.data_ptr(), F, scd.data_ptr(), shd.data_ptr(), hout.data_ptr(), F,
+                                 gwin.data_ptr(), gf.stride(0), graph_avg, y.data_ptr(), F, F,
+                                 epsd.data_ptr() if learn_eps else None, average, int(not learn_eps), _stream()),
+          "gnm_agg_fwd_bnrelu")
+    h32 = np.maximum(z * sc + sh, np.float32(0))                    # fp32, as the kernel forms it
+    assert_close(hout.cpu().numpy(), h32.astype(np.float64), rtol=1e-6, what="h = relu(bn(z))")
+    h = hout.cpu().numpy().astype(np.float64)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    ref_g = np.stack([h[off[g]:off[g + 1]].sum(0) / (sizes[g] if graph_avg else 1) for g in range(B)])
+    assert_close(gwin.cpu().numpy(), ref_g, rtol=TOL, what="readout")
+    assert torch.isnan(gf[:, :F]).all() and torch.isnan(gf[:, 2 * F:]).all()        # nothing outside the window
+    deg = np.asarray(A.sum(1)).reshape(-1, 1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if learn_eps:
+            ref = A @ h
+            if average:
+                ref = ref / deg
+            ref = ref + (1 + eps) * h
+        else:
+            ref = A @ h + h
+            if average:
+                ref = ref / (deg + 1)
+    assert_close(y.cpu().numpy(), ref, rtol=TOL, what="aggregation of the fused activation")
+
+
+def test_agg_fused_bn_relu_refuses_other_shapes():
+    from gnm._cabi import lib
+    from gnm.arena import GraphArena
+    rng = np.random.default_rng(0)
+    ar = GraphArena(DEV)
+    batch = ar.batch(random_graphs(rng, [30, 30], 0.3, True))
+    z = torch.zeros((60, 32), device=DEV)
+    v = torch.zeros(32, device=DEV)
+    assert lib.gnm_agg_fwd_bnrelu(ar.rowptr.buf.data_ptr(), ar.col.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                  batch.col_off.data_ptr(), batch.node_off.data_ptr(), 2, batch.n_max, batch.nnz_max,
+                                  z.data_ptr(), 32, v.data_ptr(), v.data_ptr(), z.data_ptr(), 32, None, 0, 0,
+                                  z.data_ptr(), 32, 32, None, 0, 1, _stream()) == -2
+
+
 # ------------------------------------------------------------------ graph-level head
 @pytest.mark.parametrize("B,L,H,C,p,with_T", [(3, 5, 64, 2, 0.5, True), (4, 3, 32, 2, 0.0, True), (1, 2, 32, 3, 0.3, False),
                                               (257, 5, 128, 2, 0.5, True), (5, 1, 20, 7, 0.0, False),

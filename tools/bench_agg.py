@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--F", type=int, default=64)
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--backward", action="store_true")
+    ap.add_argument("--fused", action="store_true",
+                    help="gnm_agg_fwd_bnrelu: previous layer's BatchNorm+ReLU+readout on the tile load (what a step runs)")
     ap.add_argument("--phase-a-only", action="store_true", help="y = null: tile load + barrier only")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -39,8 +41,18 @@ def main():
     spec = core.GinSpec(5, 2, True, "sum", "sum")
     part = torch.empty(core.lib.gnm_agg_num_partials(F, batch.n_max, batch.B), dtype=torch.float64, device=dev)
 
+    sc, sh = torch.rand(F, device=dev) + 0.5, torch.randn(F, device=dev) * 0.3
+    gf = torch.empty(batch.B, F, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
     def run():
-        if args.backward:
+        if args.fused:
+            core.check(core.lib.gnm_agg_fwd_bnrelu(
+                ar.rowptr.buf.data_ptr(), ar.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
+                batch.node_off.data_ptr(), batch.B, batch.n_max, batch.nnz_max, x.data_ptr(), F, sc.data_ptr(),
+                sh.data_ptr(), h.data_ptr(), F, gf.data_ptr(), F, 0, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, st),
+                "gnm_agg_fwd_bnrelu")
+        elif args.backward:
             core._agg(batch, x, y, F, eps.data_ptr(), spec, True, hfwd=h, deps_partial=part)
         elif args.phase_a_only:
             core._agg(batch, x, None, F, eps.data_ptr(), spec, False)
