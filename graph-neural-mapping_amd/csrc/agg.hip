@@ -156,22 +156,25 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     // time (8 independent LDS id reads, then 8 row reads) and owns its output chunk outright.
     if constexpr (LPR <= 4) {
         if (p.ids_in_lds) {
-            uint16_t* ids = reinterpret_cast<uint16_t*>(smem + (size_t)(n + 1) * (FS * 4));
+            // ids[e] = cl[e], staged with 16-B copies, 4 per thread in flight (64 KB per workgroup): with 4-B
+            // copies only 16 KB were in flight per CU and this copy alone bounded the kernel at ~2 TB/s.
+            // The LDS image is shifted by the source's misalignment so that both sides are 16-B aligned
+            // together; the copy may run up to 7 ids before / 8 ids past the graph's block (the arena keeps
+            // readable slack after the last block, and a block never starts at the buffer's first 16 bytes
+            // unless it is aligned).
+            const int mis = (int)((reinterpret_cast<uintptr_t>(cl) & 15) >> 1);          // ids before alignment
+            uint16_t* ids = reinterpret_cast<uint16_t*>(smem + (((size_t)(n + 1) * (FS * 4) + 15) & ~(size_t)15)) + mis;
             const int nnz = p.y ? rp[n] : 0;            // y == null (d-eps only): nothing to gather
-            if ((reinterpret_cast<uintptr_t>(cl) & 3) == 0) {
-                // 32-bit copies, 4 independent loads in flight per thread
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(cl);
-                uint32_t* dst = reinterpret_cast<uint32_t*>(ids);
-                const int nw = nnz >> 1;
+            {
+                const uint4* src = reinterpret_cast<const uint4*>(cl - mis);
+                uint4* dst = reinterpret_cast<uint4*>(ids - mis);
+                const int nq = (nnz + mis + 7) >> 3;
                 int e = tid;
-                for (; e + 3 * nthreads < nw; e += 4 * nthreads) {
-                    const uint32_t v0 = src[e], v1 = src[e + nthreads], v2 = src[e + 2 * nthreads], v3 = src[e + 3 * nthreads];
+                for (; e + 3 * nthreads < nq; e += 4 * nthreads) {
+                    const uint4 v0 = src[e], v1 = src[e + nthreads], v2 = src[e + 2 * nthreads], v3 = src[e + 3 * nthreads];
                     dst[e] = v0; dst[e + nthreads] = v1; dst[e + 2 * nthreads] = v2; dst[e + 3 * nthreads] = v3;
                 }
-                for (; e < nw; e += nthreads) dst[e] = src[e];
-                if ((nnz & 1) && tid == 0) ids[nnz - 1] = cl[nnz - 1];
-            } else {
-                for (int e = tid; e < nnz; e += nthreads) ids[e] = cl[e];
+                for (; e < nq; e += nthreads) dst[e] = src[e];
             }
             __syncthreads();
             const float selfB2 = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
@@ -827,9 +830,9 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
     size_t lds = (size_t)(n_max + 1) * LPR * 16;
     const int max_nnz = a.ids_in_lds;             // on entry: largest nnz of the batch (0 = unknown)
     a.ids_in_lds = 0;
-    if (LPR <= 4 && max_nnz > 0 && lds + (size_t)max_nnz * 2 + 64 <= (size_t)kLdsBudget - 1024) {
+    if (LPR <= 4 && max_nnz > 0 && lds + (size_t)max_nnz * 2 + 96 <= (size_t)kLdsBudget - 1024) {
         a.ids_in_lds = 1;
-        lds += (size_t)max_nnz * 2 + 64;
+        lds += (size_t)max_nnz * 2 + 96;          // + alignment shift and 16-B rounding of the staged id block
     }
     static size_t configured = 0;
     if (lds > configured) {
