@@ -52,11 +52,23 @@ __global__ void __launch_bounds__(256) gnm_disc_score_kernel(const HPtrs hp, int
     if constexpr (LPR4 > 0) {
         constexpr int G = 64 / LPR4;                   // rows per wave-instruction
         const int sub = lane & (LPR4 - 1), slot = lane / LPR4;
+        constexpr int ML = 8;                          // layers handled with all their loads in flight at once
+        float4 uu[ML];
+#pragma unroll
+        for (int l = 0; l < ML; ++l)
+            uu[l] = l < L ? *reinterpret_cast<const float4*>(Us + l * H + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int r = wave * G + slot; r < n + G - 1; r += 4 * G) {   // uniform trip count per wave
             const int rr = min(r, n - 1);
             const int v = row0 + rr;
             float a = 0.f;
-            for (int l = 0; l < L; ++l) {
+            float4 xx[ML];
+#pragma unroll
+            for (int l = 0; l < ML; ++l)               // L is wave-uniform: the row's loads are issued back to back
+                if (l < L) xx[l] = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);
+#pragma unroll
+            for (int l = 0; l < ML; ++l)
+                if (l < L) a += xx[l].x * uu[l].x + xx[l].y * uu[l].y + xx[l].z * uu[l].z + xx[l].w * uu[l].w;
+            for (int l = ML; l < L; ++l) {
                 const float4 x = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);
                 const float4 u = *reinterpret_cast<const float4*>(Us + l * H + 4 * sub);
                 a += x.x * u.x + x.y * u.y + x.z * u.z + x.w * u.w;

@@ -201,15 +201,8 @@ __global__ void __launch_bounds__(256) gnm_bn_relu_bwd_stats_kernel(
             }
         }
         if (dsc1) ub = *reinterpret_cast<const float4*>(U + (size_t)b * ldu + 4 * c4);
-        for (int r = rg; r < n; r += RP) {
-            const int v = row0 + r;
-            float4 t = pb;
-            if (dH) {
-                const float4 d = *reinterpret_cast<const float4*>(dH + (size_t)v * lddh + 4 * c4);
-                t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
-            }
+        auto one = [&](int v, float4 t, const float4 z, float s) {
             if (dsc1) {
-                const float s = dsc1[v];
                 t.x += s * ub.x; t.y += s * ub.y; t.z += s * ub.z; t.w += s * ub.w;
                 if (v < B) {
                     const int gq = inv_perm[v];
@@ -218,7 +211,6 @@ __global__ void __launch_bounds__(256) gnm_bn_relu_bwd_stats_kernel(
                     t.x += s2 * uq.x; t.y += s2 * uq.y; t.z += s2 * uq.z; t.w += s2 * uq.w;
                 }
             }
-            const float4 z = *reinterpret_cast<const float4*>(Z + (size_t)v * ldz + 4 * c4);
             if (relu) {
                 if (!(z.x * sc.x + sh.x > 0.f)) t.x = 0.f;
                 if (!(z.y * sc.y + sh.y > 0.f)) t.y = 0.f;
@@ -229,6 +221,34 @@ __global__ void __launch_bounds__(256) gnm_bn_relu_bwd_stats_kernel(
             a1.x += t.x; a1.y += t.y; a1.z += t.z; a1.w += t.w;
             a2.x += t.x * ((z.x - mu.x) * rs.x); a2.y += t.y * ((z.y - mu.y) * rs.y);
             a2.z += t.z * ((z.z - mu.z) * rs.z); a2.w += t.w * ((z.w - mu.w) * rs.w);
+        };
+        constexpr int UR = 4;                       // rows per thread with all their loads in flight
+        int r = rg;
+        for (; r + (UR - 1) * RP < n; r += UR * RP) {
+            float4 zz[UR], dd[UR];
+            float ss[UR];
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const int v = row0 + r + u * RP;
+                zz[u] = *reinterpret_cast<const float4*>(Z + (size_t)v * ldz + 4 * c4);
+                dd[u] = dH ? *reinterpret_cast<const float4*>(dH + (size_t)v * lddh + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                ss[u] = dsc1 ? dsc1[v] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                float4 t = pb;
+                t.x += dd[u].x; t.y += dd[u].y; t.z += dd[u].z; t.w += dd[u].w;
+                one(row0 + r + u * RP, t, zz[u], ss[u]);
+            }
+        }
+        for (; r < n; r += RP) {
+            const int v = row0 + r;
+            float4 t = pb;
+            if (dH) {
+                const float4 d = *reinterpret_cast<const float4*>(dH + (size_t)v * lddh + 4 * c4);
+                t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
+            }
+            one(v, t, *reinterpret_cast<const float4*>(Z + (size_t)v * ldz + 4 * c4), dsc1 ? dsc1[v] : 0.f);
         }
         red[rg * H4 + c4] = a1;
         red[(RP + rg) * H4 + c4] = a2;
