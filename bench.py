@@ -13,7 +13,8 @@ every rank owns `--batch` graphs per step (weak scaling, configs[2] at --batch 5
 step ends with ONE RCCL all-reduce of the flat gradient buffer.
 
 Prints one JSON line (rank 0).  Extra objects:
-  roofline      the sum-aggregation kernel at F = 64 (forward launches): algorithmic bytes
+  roofline      the sum-aggregation kernel at F = 64 (forward launches, as the step runs them: with the
+                previous layer's BatchNorm+ReLU+readout on the tile load): algorithmic bytes
                 (396,804 B per graph-layer) / mean launch duration from
                 HIP events on the launch stream, against 8 TB/s.
   roofline_mlp  the fp32-MFMA Linear(64,64) forward launches against 157.3 TFLOP/s.
@@ -32,6 +33,9 @@ PKG = os.path.join(ROOT, "graph-neural-mapping_amd")
 for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
+# multi-process GPU work on this pool needs dmabuf IPC (already exported on the boxes; kept if the launcher's
+# environment was rebuilt) -- must be set before the HIP runtime initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
