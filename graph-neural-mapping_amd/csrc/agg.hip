@@ -442,7 +442,10 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     double dot = 0.0;
     const int total = n * LPR;
     constexpr int UNR = 4;
-    const bool fast = vec_in && (col0 + FS <= p.F) && (!p.deps_partial || vec_h);
+    // d eps: either dot(x, hfwd) on the way in (hfwd given), or -- STATS launches -- from the rows the epilogue
+    // already holds: x's own row and h recomputed from the layer below's Z (no pass over hfwd at all)
+    const bool dot_a = p.deps_partial && p.hfwd;
+    const bool fast = vec_in && (col0 + FS <= p.F) && (!dot_a || vec_h);
     int base = tid;
     // forward prologue (non-STATS launches of gnm_agg_fwd_bnrelu only; nthreads is a multiple of 16, so a
     // thread keeps the column chunk tid & 15 for all its rows)
@@ -499,7 +502,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 const size_t off = (size_t)(row0 + (i >> 4)) * p.ldx + col0 + 4 * (i & 15);
                 v[u] = *reinterpret_cast<const float4*>(p.x + off);
             }
-            if (p.deps_partial) {
+            if (dot_a) {
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const int i = base + u * nthreads;
@@ -538,7 +541,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
             if (cc + 2 < p.F) w.z = src[2];
             if (cc + 3 < p.F) w.w = src[3];
         }
-        if (p.deps_partial) {
+        if (dot_a) {
             const float* hs = p.hfwd + (size_t)(row0 + r) * p.ldh + cc;
             float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (vec_h && cc + 3 < p.F) {
@@ -728,6 +731,14 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                         sb.w = (cc + 3 < p.F) ? src[3] : 0.f;
                     }
                     tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
+                    if constexpr (STATS) {
+                        if (p.deps_partial && !p.hfwd) {
+                            // d eps += dpooled[v] . h[v], h = relu(bn_lo(Z[v])) recomputed as the forward formed it
+                            const float hx = fmaxf(zrow.x * lsc.x + lsh.x, 0.f), hy = fmaxf(zrow.y * lsc.y + lsh.y, 0.f);
+                            const float hz = fmaxf(zrow.z * lsc.z + lsh.z, 0.f), hw = fmaxf(zrow.w * lsc.w + lsh.w, 0.f);
+                            dot += (double)(sb.x * hx + sb.y * hy) + (double)(sb.z * hz + sb.w * hw);
+                        }
+                    }
                 }
                 if constexpr (STATS) {
                     // total gradient at this layer output = aggregation backward + readout + discriminator terms
@@ -921,7 +932,8 @@ extern "C" int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, con
                          reinterpret_cast<uintptr_t>(s_rstd) | reinterpret_cast<uintptr_t>(dpool) |
                          reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(y);
     if (al & 15) return GNM_ERR_UNSUPPORTED;
-    if (deps_partial && !hfwd) return GNM_ERR_BAD_ARG;
+    // deps_partial with hfwd == NULL: h is recomputed from sZ in the epilogue (needs the (1+eps) self-term form)
+    if (deps_partial && !hfwd && self_loop) return GNM_ERR_BAD_ARG;
     AggArgs a = g_stats_none();
     a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
     a.deg_rowptr = deg_rowptr ? deg_rowptr : rowptr;

@@ -549,8 +549,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                             batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
                             batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, dpooled.data_ptr(),
                             dpooled.stride(0), dh.data_ptr(), dh.stride(0), F_l, eps_ptr, int(spec.n_avg),
-                            int(not spec.learn_eps), ptr(h_in) if spec.learn_eps else None,
-                            h_in.stride(0) if spec.learn_eps else 0, ptr(part), lo.z.data_ptr(), lo.z.stride(0),
+                            int(not spec.learn_eps), None, 0,      # h_in is recomputed from lo.z in the epilogue (d eps)
+                            ptr(part), lo.z.data_ptr(), lo.z.stride(0),
                             lo.scale.data_ptr(), lo.shift.data_ptr(), lo.mean.data_ptr(), lo.rstd.data_ptr(),
                             ptr(dplo), dplo.stride(0) if dplo is not None else 0, int(spec.g_avg),
                             ptr(dsc1) if use_disc else None, ptr(Ulo), U.stride(0) if use_disc else 0,

@@ -76,7 +76,9 @@ int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
  * for the BatchNorm+ReLU that produced that layer output (graphcnn.py:163-166 of the layer below): y becomes
  * G = (A^T x [+ self terms] + w_b*dpool[b] + dsc1[v]*U[b] + quirk rows) * relu-mask(sZ), and s_partial receives
  * [B][2][64] doubles (sum G, sum G*xhat) for gnm_bn_bwd_finalize.  Only for F = 64 with the whole [n, 64] tile
- * in LDS; GNM_ERR_UNSUPPORTED otherwise (nothing is launched).  dpool / dsc1 (with U, inv_perm, s2sum) may be null. */
+ * in LDS; GNM_ERR_UNSUPPORTED otherwise (nothing is launched).  dpool / dsc1 (with U, inv_perm, s2sum) may be null.
+ * deps_partial with hfwd == NULL (learn_eps form only): the layer input h = relu(sZ*s_scale+s_shift) is recomputed in
+ * the epilogue from the sZ row it already holds, so d eps costs no pass over h. */
 int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
                       const int32_t* deg_rowptr, const int64_t* b_deg_off, const int32_t* node_off, int B, int n_max,
                       int nnz_max, const float* x, int ldx, float* y, int ldy, int F, const float* eps, int average,

@@ -190,6 +190,24 @@ def test_agg_backward_fused_with_bn_stats(sizes, density, average, learn_eps, gr
     assert_close(p_f.cpu().numpy(), p_ref.cpu().numpy(), rtol=TOL, what="BN-backward partial sums", floor=fl)
     if learn_eps:
         assert torch.equal(part_f, part_e)                   # the d-eps partials are untouched by the fusion
+        # hfwd = NULL: the layer input is recomputed in the epilogue as relu(Z*scale+shift); G and the BatchNorm
+        # sums must not change and the partials must add up to sum dpooled . h in fp64
+        G2 = torch.full((N, F), float("nan"), device=DEV)
+        p2 = torch.full((B, 2, F), float("nan"), dtype=torch.float64, device=DEV)
+        part2 = torch.full_like(part_e, float("nan"))
+        check(lib.gnm_agg_bwd_stats(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
+                                    batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                    batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, dp.data_ptr(), F,
+                                    G2.data_ptr(), F, F, epsp, average, 0, None, 0, part2.data_ptr(), Z.data_ptr(), F,
+                                    sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), dpool.data_ptr(), F,
+                                    graph_avg, dsc1.data_ptr() if disc else None, Ul.data_ptr() if disc else None,
+                                    U.stride(0) if disc else 0, invd.data_ptr() if disc else None,
+                                    s2.data_ptr() if disc else None, p2.data_ptr(), _stream()), "agg_bwd_stats (h from Z)")
+        assert torch.equal(G2, G) and torch.equal(p2, p_f)
+        h_re = np.maximum(Z.cpu().numpy() * sc.cpu().numpy() + sh.cpu().numpy(), np.float32(0)).astype(np.float64)
+        want = float((dp.cpu().numpy().astype(np.float64) * h_re).sum())
+        scale_ = float(np.abs(dp.cpu().numpy().astype(np.float64) * h_re).sum())
+        assert abs(float(part2.sum().item()) - want) <= 2e-6 * scale_
     # shapes it does not cover are refused
     assert lib.gnm_agg_bwd_stats(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
                                  batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
