@@ -377,10 +377,25 @@ __global__ void __launch_bounds__(256) gnm_rowdot_partials_kernel(const float* _
     __shared__ double lds[4];
     const long long total = N * F;
     double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long r = i / F;
-        const int c = (int)(i - r * F);
-        acc += (double)(A[r * lda + c] * Bm[r * ldb + c]);
+    if (lda == F && ldb == F && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(Bm)) & 15) == 0) {
+        // both operands are dense row-major: one flat dot product, 16-B loads
+        const long long n4 = total >> 2;
+        const float4* a4 = reinterpret_cast<const float4*>(A);
+        const float4* b4 = reinterpret_cast<const float4*>(Bm);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const float4 x = a4[i], y = b4[i];
+            acc += (double)(x.x * y.x + x.y * y.y) + (double)(x.z * y.z + x.w * y.w);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (int)(total & 3)) {
+            const long long i = (n4 << 2) + threadIdx.x;
+            acc += (double)(A[i] * Bm[i]);
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const long long r = i / F;
+            const int c = (int)(i - r * F);
+            acc += (double)(A[r * lda + c] * Bm[r * ldb + c]);
+        }
     }
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;

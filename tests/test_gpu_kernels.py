@@ -532,6 +532,21 @@ def test_agg_fused_bn_relu_refuses_other_shapes():
                                   z.data_ptr(), 32, 32, None, 0, 1, _stream()) == -2
 
 
+@pytest.mark.parametrize("N,F,pad", [(1200, 7, 0), (1203, 7, 0), (37, 64, 0), (500, 7, 5), (1, 3, 0)])
+def test_rowdot_partials(N, F, pad):
+    """gnm_rowdot_partials (d eps of a layer whose aggregation backward has no other consumer): sum_v A[v,:].B[v,:]
+    in fp64 partials, dense (flat 16-B path) and strided operands."""
+    from gnm._cabi import check, lib
+    rng = np.random.default_rng(N + F)
+    A = torch.from_numpy(rng.standard_normal((N, F + pad)).astype(np.float32)).to(DEV)
+    Bm = torch.from_numpy(rng.standard_normal((N, F + pad)).astype(np.float32)).to(DEV)
+    part = torch.full((lib.gnm_rowdot_num_partials(),), float("nan"), dtype=torch.float64, device=DEV)
+    check(lib.gnm_rowdot_partials(A.data_ptr(), F + pad, Bm.data_ptr(), F + pad, N, F, part.data_ptr(), _stream()), "rowdot")
+    a, b = A[:, :F].cpu().numpy().astype(np.float64), Bm[:, :F].cpu().numpy().astype(np.float64)
+    want, scale = float((a * b).sum()), float(np.abs(a * b).sum())
+    assert abs(float(part.sum().item()) - want) <= 2e-6 * scale
+
+
 # ------------------------------------------------------------------ graph-level head
 @pytest.mark.parametrize("B,L,H,C,p,with_T", [(3, 5, 64, 2, 0.5, True), (4, 3, 32, 2, 0.0, True), (1, 2, 32, 3, 0.3, False),
                                               (257, 5, 128, 2, 0.5, True), (5, 1, 20, 7, 0.0, False),
