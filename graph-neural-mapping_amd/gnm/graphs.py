@@ -54,6 +54,13 @@ class CapturedTrainStep:
             for t, s0 in zip(keep, snapshot):
                 t.copy_(s0)
         torch.cuda.synchronize()
+        self._arena_ptrs = self._arena_buffers()
+
+    def _arena_buffers(self):
+        """addresses the captured kernels read the graph pool from: adding graphs may re-allocate them"""
+        a = self.static.batch.arena
+        return (a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), a.feat.buf.data_ptr(),
+                tuple(sorted((k, v["buf"].data_ptr()) for k, v in a._agg0.items() if v["buf"] is not None)))
 
     def _step(self):
         self._zero()
@@ -71,6 +78,9 @@ class CapturedTrainStep:
         np.random.permutation(B) of graphcnn.py:199 (drawn here if None)."""
         if perm is None:
             perm = np.random.permutation(batch.B)
+        if self._arena_buffers() != self._arena_ptrs:
+            raise RuntimeError("the graph arena was re-allocated after this step was captured (graphs were added): "
+                               "add every graph before building CapturedTrainStep / FusedTrainStep, or build a new one")
         self.static.load(batch)
         self.labels.copy_(labels, non_blocking=True)
         self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)

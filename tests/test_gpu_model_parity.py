@@ -492,3 +492,28 @@ def test_layer0_aggregate_cache_equals_direct_aggregation(learn_eps, npool):
             assert abs(outs[0][2]["eps"][0]) > 0
     X, P0 = ar.features_and_agg0(bt, npool == "average", not learn_eps)
     assert P0 is not None and P0.shape == X.shape
+
+
+def test_captured_step_refuses_a_reallocated_arena():
+    """A captured step holds raw addresses of the arena's buffers: growing the arena afterwards must be reported,
+    not silently read through stale pointers."""
+    from gnm import synth
+    from gnm.graphs import CapturedTrainStep
+    from gnm.train import infomax_loss
+    from models.graphcnn import GIN_InfoMaxReg
+    dev = torch.device(DEV)
+    pool = synth.make_pool("dense_fc", 4, n=40, t=64, f0=7)
+    torch.manual_seed(0)
+    m = GIN_InfoMaxReg(2, 2, 7, 32, 2, 0.0, True, "sum", "sum", dev).to(dev).train()
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    ar = m.arena()
+    gids = np.array([ar.add(g) for g in pool], dtype=np.int64)
+    bt = ar.batch_from_gids(gids)
+    lab = torch.zeros(4, dtype=torch.int64, device=dev)
+    cap = CapturedTrainStep(m, bt, lambda c, d, l: infomax_loss(c, d, l)[0])
+    cap.run(bt, lab, np.arange(4))
+    for g in synth.make_pool("dense_fc", 300, first=100, n=40, t=64, f0=7):      # enough to outgrow the buffers
+        ar.add(g)
+    with pytest.raises(RuntimeError, match="re-allocated"):
+        cap.run(ar.batch_from_gids(gids), lab, np.arange(4))
