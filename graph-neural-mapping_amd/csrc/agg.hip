@@ -89,6 +89,13 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
 
 #define GNM_STEP16(S) acc4(acc, lds_read16(row_bcast16<S>(valb) + subb));
 
+// Column id at (uniform base, per-lane 32-bit index): written as base + zero-extended BYTE offset so the load
+// takes the SGPR-base + 32-bit VGPR-offset form (one v_lshl_add_u32 per load instead of a 64-bit address built
+// from three VALU instructions).  A graph's block holds < 2^30 ids.
+__device__ __forceinline__ unsigned load_id(const uint16_t* base, unsigned byte_off) {
+    return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 template <int LPR>
 __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     constexpr int FS = LPR * 4;        // floats per LDS row
@@ -633,7 +640,8 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         // addresses when the row becomes current, so the wait is a counted vmcnt at the use.
         // The loads are unconditional (the arena keeps >= 128 readable ids past the last
         // block): a load inside a divergent branch would be drained (vmcnt(0)) at the join.
-        unsigned nra = cl[nbeg + jlane], nrb = cl[nbeg + 64 + jlane];
+        const unsigned jl2 = 2u * (unsigned)jlane;
+        unsigned nra = load_id(cl, 2u * (unsigned)nbeg + jl2), nrb = load_id(cl, 2u * (unsigned)nbeg + 128u + jl2);
         for (int kk = 0; kk < ng; ++kk) {
             const int g = wave + (k0 + kk) * nwaves;
             // this quarter's own row (for the self term): read it NOW, ahead of the gather, so it
@@ -666,8 +674,8 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                     nend = nbeg;                               // nothing follows: an empty row at a valid address
                 }
                 if (!(p.debug & 1)) {
-                    nra = cl[nbeg + jlane];
-                    nrb = cl[nbeg + 64 + jlane];
+                    nra = load_id(cl, 2u * (unsigned)nbeg + jl2);
+                    nrb = load_id(cl, 2u * (unsigned)nbeg + 128u + jl2);
                 }
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 int cnt = end - beg;
@@ -696,7 +704,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                     if (e0 == beg + 64) {
                         valb = ib;                             // second chunk was prefetched
                     } else {                                   // degree > 128: fetch in place
-                        const unsigned rc = cl[e0 + jlane];
+                        const unsigned rc = load_id(cl, 2u * (unsigned)e0 + jl2);
                         valb = (jlane < cnt) ? rc * (FS * 4) : zero_row_b;
                     }
                 }
