@@ -592,6 +592,8 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
     const bool vec_out = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
     const int ngroups = p.y ? (n + 3) >> 2 : 0;
+    const bool need_deg = !p.backward && p.average;
+    const int qm1 = -(q & 1), qm2 = -(q >> 1);               // all-ones masks selecting this lane's quarter
     // fused BatchNorm-backward statistics of the layer below (STATS): per-lane column chunk `sub`
     float4 ss1 = make_float4(0.f, 0.f, 0.f, 0.f), ss2 = ss1, s_pb = ss1, s_ub = ss1;
     float4 lsc = ss1, lsh = ss1, lmu = ss1, lrs = ss1;
@@ -655,11 +657,18 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 zrow = *reinterpret_cast<const float4*>(p.sZ + (size_t)vc * p.ldsz + 4 * sub);
                 if (p.s_dsc1) dsc_v = p.s_dsc1[vc];
             }
-            // degree of row v from the rowptr lane vector (no LDS): 5 readlanes + selects
-            const int b0 = __builtin_amdgcn_readlane(rpv, 8 * kk), b1 = __builtin_amdgcn_readlane(rpv, 8 * kk + 1),
-                      b2 = __builtin_amdgcn_readlane(rpv, 8 * kk + 2), b3 = __builtin_amdgcn_readlane(rpv, 8 * kk + 3),
-                      b4 = __builtin_amdgcn_readlane(rpv, 8 * kk + 4);
-            const int degv = (q == 0) ? b1 - b0 : (q == 1) ? b2 - b1 : (q == 2) ? b3 - b2 : b4 - b3;
+            // degree of row v (forward "average" only) from the rowptr lane vector (no LDS): 5 readlanes, then a
+            // branch-free per-quarter select (written as a ?: chain it compiled to ~40 exec-mask/branch
+            // instructions per group, on every launch)
+            int degv = 0;
+            if (need_deg) {                                    // wave-uniform
+                const int b0 = __builtin_amdgcn_readlane(rpv, 8 * kk), b1 = __builtin_amdgcn_readlane(rpv, 8 * kk + 1),
+                          b2 = __builtin_amdgcn_readlane(rpv, 8 * kk + 2), b3 = __builtin_amdgcn_readlane(rpv, 8 * kk + 3),
+                          b4 = __builtin_amdgcn_readlane(rpv, 8 * kk + 4);
+                const int d0 = b1 - b0, d1 = b2 - b1, d2 = b3 - b2, d3 = b4 - b3;
+                const int lo = (d0 & ~qm1) | (d1 & qm1), hi = (d2 & ~qm1) | (d3 & qm1);
+                degv = (lo & ~qm2) | (hi & qm2);
+            }
             float4 racc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
