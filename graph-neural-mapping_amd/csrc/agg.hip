@@ -424,6 +424,11 @@ template <bool STATS>
 __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     constexpr int LPR = 16;
     constexpr int FS = 64;
+#ifdef GNM_AGG16_TUNING       // tools/bench_agg.py ablations (GNM_AGG16_DEBUG); compiled out of the product kernel
+    const int dbg = p.debug;
+#else
+    constexpr int dbg = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* tile = reinterpret_cast<float4*>(smem);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -617,7 +622,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     // cycles deep, so row bounds come from a lane vector loaded once per 8 groups
     // (v_readlane), column ids are fetched one row ahead, and the 4-row combine below is
     // pure VALU (v_permlane32_swap / v_permlane16_swap).
-    if (p.debug & 8) {   // tuning: the micro-benchmark's steady-state loop, same step count (2 x 16 per row)
+    if (dbg & 8) {   // tuning: the micro-benchmark's steady-state loop, same step count (2 x 16 per row)
         unsigned valb = (unsigned)((lane * 37 + 11) % max(n, 1)) * (FS * 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int g = wave; g < ngroups; g += nwaves)
@@ -682,7 +687,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 } else {
                     nend = nbeg;                               // nothing follows: an empty row at a valid address
                 }
-                if (!(p.debug & 1)) {
+                if (!(dbg & 1)) {
                     nra = load_id(cl, 2u * (unsigned)nbeg + jl2);
                     nrb = load_id(cl, 2u * (unsigned)nbeg + 128u + jl2);
                 }
@@ -721,7 +726,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
             }
             // transposing combine: afterwards quarter q holds the full sum of row 4g + q
             float4 tot;
-            if (p.debug & 4) {
+            if (dbg & 4) {
                 tot = racc[0]; acc4(tot, racc[1]); acc4(tot, racc[2]); acc4(tot, racc[3]);
             } else {
                 const float4 t02 = swap_add32(racc[0], racc[2]);   // lanes 0-31: row 0, lanes 32-63: row 2
@@ -729,7 +734,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 tot = swap_add16(t02, t13);
             }
 
-            if (p.debug & 2) {
+            if (dbg & 2) {
                 if (tot.x == 12345.678f) p.y[0] = tot.y + tot.z + tot.w + self.x;   // keep values live
             } else if (v < n) {
                 if (p.self_loop) acc4(tot, self);
