@@ -375,6 +375,11 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     }
 
 #define GNM_RD(S) lds_read16(row_bcast16<S>(valb) + subb)
+#define GNM_PAIR(S0)                                                      \
+    {                                                                     \
+        const f32x4 p0_ = GNM_RD(S0), p1_ = GNM_RD(S0 + 1);               \
+        acc4(acc, p0_ + p1_);                                             \
+    }
 #define GNM_BLOCK8(H)                                                                                   \
     {                                                                                                   \
         const f32x4 a0_ = GNM_RD(8 * H + 0), a1_ = GNM_RD(8 * H + 1), a2_ = GNM_RD(8 * H + 2),           \
@@ -702,11 +707,17 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                     const int steps = (c64 + 3) >> 2;          // wave-uniform
                     // 16 ds_read_b128 in flight per block; the STATS variant needs the 32 registers and uses
                     // two 8-deep blocks (measured within noise of 16-deep at 16 waves/CU)
-                    if (steps > 12 && !STATS) {
+                    // (13 or 14 steps -- half of the second chunks at mean degree 119 -- stop at 14 reads, not 16)
+                    if (steps > 14 && !STATS) {
                         GNM_BLOCK16()
                     } else if (steps > 8) {
                         GNM_BLOCK8(0)
-                        if (steps > 12) GNM_BLOCK8(1) else GNM_GROUP4(2)
+                        if (steps > 14) {
+                            GNM_BLOCK8(1)
+                        } else {
+                            GNM_GROUP4(2)
+                            if (steps > 12) GNM_PAIR(12)
+                        }
                     } else if (steps > 4) {
                         GNM_BLOCK8(0)
                     } else {
