@@ -104,6 +104,27 @@ class GIN_InfoMaxReg(nn.Module):
             return g_f.detach().cpu().numpy()                                  # graphcnn.py:248-249
         return c_logit, d_logit
 
+    @torch.no_grad()
+    def predict(self, graphs, batch_size=256, latent=False):
+        """Evaluation over many graphs in batches (not in the reference: its test() / get_latent_space() call
+        forward([g]) once per graph, main.py:49-57,71-82, which is launch-bound).  Eval mode -- BatchNorm uses its
+        running statistics, so batching does not change a graph's result.  Returns c_logit [len(graphs), C], or
+        the [len(graphs), L*H] latent array when latent=True.  Graphs of a batch must have equal node counts
+        (discriminator.py:24), as in forward()."""
+        was_training = self.training
+        self.eval()
+        try:
+            out = []
+            for i in range(0, len(graphs), batch_size):
+                chunk = graphs[i:i + batch_size]
+                r = self.forward(chunk, latent=latent)
+                out.append(r if latent else r[0])
+            if latent:
+                return np.concatenate(out, 0) if out else np.zeros((0, 0), dtype=np.float32)
+            return torch.cat(out, 0) if out else torch.zeros((0, 0), device=self.eps.device)
+        finally:
+            self.train(was_training)
+
     # ------------------------------------------------------------------ reference API
     def forward(self, batch_graph, latent=False):
         if self.neighbor_pooling_type == "max":

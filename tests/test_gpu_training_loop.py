@@ -66,7 +66,13 @@ def test_training_loop_learns_and_eval_paths_work(tmp_path):
     acc = float((pred == np.array([g.label for g in test_graphs])).mean())
     assert acc >= 0.8, acc
 
+    # batched evaluation gives the per-graph results (eval-mode BatchNorm: no cross-graph coupling)
+    batched = model.predict(test_graphs, batch_size=5)
+    assert batched.shape == (len(test_graphs), 2)
+    assert float((batched - torch.cat(outs, 0)).abs().max()) <= 1e-5 * float(torch.cat(outs, 0).abs().max())
+    assert not model.training
     latent = np.concatenate([model([g], latent=True) for g in test_graphs], 0)      # main.py:71-82
+    assert np.abs(model.predict(test_graphs, batch_size=7, latent=True) - latent).max() <= 1e-5 * np.abs(latent).max()
     assert latent.shape == (len(test_graphs), 3 * 32) and np.isfinite(latent).all()
     sal = np.stack([model.compute_saliency([g], 1).detach().cpu().numpy() for g in test_graphs[:3]], 0)
     assert sal.shape == (3, n, 7) and np.isfinite(sal).all() and np.abs(sal).max() > 0
