@@ -72,6 +72,14 @@ __device__ __forceinline__ unsigned row_bcast16(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + S, 0xf, 0xf, false);
 }
 
+template <int S>
+__device__ __forceinline__ unsigned bcast8(unsigned v) {
+    // 8-lane groups: lanes 0-7 of each 16-lane DPP row read lane S of the row, lanes 8-15 read lane 8 + S
+    int r = __builtin_amdgcn_update_dpp(0, (int)v, 0x150 + S, 0xf, 0x3, false);
+    r = __builtin_amdgcn_update_dpp(r, (int)v, 0x150 + 8 + S, 0xf, 0xc, false);
+    return (unsigned)r;
+}
+
 __device__ __forceinline__ void acc4(float4& a, const float4 v) {
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
 }
@@ -154,6 +162,11 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
         tile[i] = v;
     }
     if (tid < LPR) tile[n * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // row n = zeros (padding slots)
+    // row offsets staged behind the tile (wave-cooperative path only: the narrow path keeps its id block there)
+    int* rp_s = reinterpret_cast<int*>(smem + (size_t)(n + 1) * (FS * 4));
+    const bool stage_rp = !(LPR <= 4 && p.ids_in_lds);
+    if (stage_rp)
+        for (int i = tid; i <= n; i += nthreads) rp_s[i] = rp[i];
     __syncthreads();
 
     // ---- phase B, narrow features (FS <= 16 floats): one THREAD per (row, 16-B chunk) ------
@@ -255,44 +268,55 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
     const bool vec_out = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
 
-    // y == null: only the d-eps dot product of phase A is wanted
-    for (int v = p.y ? wave : n; v < n; v += nwaves) {
-        const int beg = rp[v];
-        const int end = rp[v + 1];
+    // y == null: only the d-eps dot product of phase A is wanted.
+    // Nothing on the per-row path is a dependent global round trip: the row bounds come from LDS two rows ahead,
+    // the row's first 64 column ids are requested one row ahead (unconditional loads: the arena keeps readable
+    // slack behind the last block), and the ids of a chunk reach the lane groups either by DPP (8-lane groups: two
+    // bank-masked row_newbcast moves, no LDS round trip) or by a BATCH of ds_bpermute issued before the reads.
+    const unsigned jl2 = 2u * (unsigned)jlane;
+    int v = p.y ? wave : n;
+    int nb = 0, ne = 0, nnb = 0, nne = 0;
+    unsigned nraw = 0;
+    if (v < n) {
+        nb = rp_s[v]; ne = rp_s[v + 1];
+        nraw = load_id(cl, 2u * (unsigned)nb + jl2);
+        if (v + nwaves < n) { nnb = rp_s[v + nwaves]; nne = rp_s[v + nwaves + 1]; }
+    }
+    for (; v < n; v += nwaves) {
+        const int beg = nb, end = ne;
+        unsigned raw = nraw;
+        nb = nnb; ne = nne;
+        if (v + nwaves < n) nraw = load_id(cl, 2u * (unsigned)nb + jl2);          // wave-uniform branch
+        if (v + 2 * nwaves < n) { nnb = rp_s[v + 2 * nwaves]; nne = rp_s[v + 2 * nwaves + 1]; }
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int e0 = beg; e0 < end; e0 += 64) {
             const int cnt = min(64, end - e0);
-            unsigned valb = zero_row_b;
-            if (jlane < cnt) valb = (unsigned)cl[e0 + jlane] * (FS * 4);
-            const int steps = (cnt + SLOTS - 1) / SLOTS;   // wave-uniform
-            if constexpr (LPR == 16) {
-                if (steps == 16) {
-                    GNM_STEP16(0) GNM_STEP16(1) GNM_STEP16(2) GNM_STEP16(3)
-                    GNM_STEP16(4) GNM_STEP16(5) GNM_STEP16(6) GNM_STEP16(7)
-                    GNM_STEP16(8) GNM_STEP16(9) GNM_STEP16(10) GNM_STEP16(11)
-                    GNM_STEP16(12) GNM_STEP16(13) GNM_STEP16(14) GNM_STEP16(15)
-                } else {
-                    if (steps > 0) GNM_STEP16(0)
-                    if (steps > 1) GNM_STEP16(1)
-                    if (steps > 2) GNM_STEP16(2)
-                    if (steps > 3) GNM_STEP16(3)
-                    if (steps > 4) GNM_STEP16(4)
-                    if (steps > 5) GNM_STEP16(5)
-                    if (steps > 6) GNM_STEP16(6)
-                    if (steps > 7) GNM_STEP16(7)
-                    if (steps > 8) GNM_STEP16(8)
-                    if (steps > 9) GNM_STEP16(9)
-                    if (steps > 10) GNM_STEP16(10)
-                    if (steps > 11) GNM_STEP16(11)
-                    if (steps > 12) GNM_STEP16(12)
-                    if (steps > 13) GNM_STEP16(13)
-                    if (steps > 14) GNM_STEP16(14)
+            if (e0 != beg) raw = load_id(cl, 2u * (unsigned)e0 + jl2);             // degree > 64: fetched in place
+            const unsigned valb = (jlane < cnt) ? raw * (FS * 4) : zero_row_b;
+            const int steps = (cnt + SLOTS - 1) / SLOTS;   // wave-uniform, <= LPR
+            if constexpr (LPR == 8) {
+                // padding slots read the zero row: blocks of 4 run unguarded, 4 reads in flight each
+                {
+                    const f32x4 t0 = lds_read16(bcast8<0>(valb) + subb), t1 = lds_read16(bcast8<1>(valb) + subb),
+                                t2 = lds_read16(bcast8<2>(valb) + subb), t3 = lds_read16(bcast8<3>(valb) + subb);
+                    acc4(acc, (t0 + t1) + (t2 + t3));
+                }
+                if (steps > 4) {
+                    const f32x4 t0 = lds_read16(bcast8<4>(valb) + subb), t1 = lds_read16(bcast8<5>(valb) + subb),
+                                t2 = lds_read16(bcast8<6>(valb) + subb), t3 = lds_read16(bcast8<7>(valb) + subb);
+                    acc4(acc, (t0 + t1) + (t2 + t3));
                 }
             } else {
                 const int gbase = lane & ~(LPR - 1);
-                for (int s = 0; s < steps; ++s) {
-                    acc4(acc, lds_read16((unsigned)__shfl((int)valb, gbase + s, 64) + subb));
+                int s = 0;
+                for (; s + 4 <= steps; s += 4) {
+                    const unsigned a0 = (unsigned)__shfl((int)valb, gbase + s, 64), a1 = (unsigned)__shfl((int)valb, gbase + s + 1, 64),
+                                   a2 = (unsigned)__shfl((int)valb, gbase + s + 2, 64), a3 = (unsigned)__shfl((int)valb, gbase + s + 3, 64);
+                    const f32x4 t0 = lds_read16(a0 + subb), t1 = lds_read16(a1 + subb), t2 = lds_read16(a2 + subb),
+                                t3 = lds_read16(a3 + subb);
+                    acc4(acc, (t0 + t1) + (t2 + t3));
                 }
+                for (; s < steps; ++s) acc4(acc, lds_read16((unsigned)__shfl((int)valb, gbase + s, 64) + subb));
             }
         }
         // combine the SLOTS partial sums of this destination row
@@ -877,6 +901,8 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
     if (LPR <= 4 && max_nnz > 0 && lds + (size_t)max_nnz * 2 + 96 <= (size_t)kLdsBudget - 1024) {
         a.ids_in_lds = 1;
         lds += (size_t)max_nnz * 2 + 96;          // + alignment shift and 16-B rounding of the staged id block
+    } else {
+        lds += (size_t)(n_max + 2) * 4 + 16;       // staged row offsets (gnm_agg_slice_width budgets for them)
     }
     static size_t configured = 0;
     if (lds > configured) {
