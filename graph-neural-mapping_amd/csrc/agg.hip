@@ -72,6 +72,31 @@ __device__ __forceinline__ unsigned row_bcast16(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + S, 0xf, 0xf, false);
 }
 
+// x' + y' after v_permlane32_swap: lanes 0-31 get x[l] + x[l+32], lanes 32-63 get y[l-32] + y[l]
+__device__ __forceinline__ float swap_add32_1(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float4 swap_add32(const float4 x, const float4 y) {
+    return make_float4(swap_add32_1(x.x, y.x), swap_add32_1(x.y, y.y), swap_add32_1(x.z, y.z), swap_add32_1(x.w, y.w));
+}
+// after v_permlane16_swap: 16-lane rows 0,2 get x[row]+x[row+1], rows 1,3 get y[row-1]+y[row]
+__device__ __forceinline__ float swap_add16_1(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float4 swap_add16(const float4 x, const float4 y) {
+    return make_float4(swap_add16_1(x.x, y.x), swap_add16_1(x.y, y.y), swap_add16_1(x.z, y.z), swap_add16_1(x.w, y.w));
+}
+
+// x[l ^ 8] within each 16-lane DPP row (row_ror:8)
+__device__ __forceinline__ float ror8(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
+}
+// lane-indexed read of a lane vector (per-lane index i < 16): v[i] -- two 16-lane-row broadcasts would need a uniform
+// index, so this is a ds_bpermute; used once per 8-row group (degree for "average" only)
+__device__ __forceinline__ int bnd_of(int v, int i) { return __shfl(v, i, 64); }
+
 template <int S>
 __device__ __forceinline__ unsigned bcast8(unsigned v) {
     // 8-lane groups: lanes 0-7 of each 16-lane DPP row read lane S of the row, lanes 8-15 read lane 8 + S
@@ -268,6 +293,91 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
     const bool vec_out = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
 
+    // ---- 32-float slices (8 lanes per row, 8 neighbours per wave-instruction): GROUPS OF 8 ROWS per wave ----------
+    // Row r of a group is gathered by all 8 lane groups (each takes every 8th neighbour); the 8 x 8 partial sums are
+    // then combined by a transposing butterfly -- v_permlane32_swap, v_permlane16_swap, DPP row_ror:8 -- after which lane
+    // group k owns the whole sum of row k and all 64 lanes run the epilogue and store 1 KiB.  No ds_bpermute and no
+    // per-row global round trip: the 9 row offsets come from LDS as a lane vector fetched one group ahead, the 8 id
+    // chunks of a group are requested together.
+    if constexpr (LPR == 8) {
+        const int ngroups = p.y ? (n + 7) >> 3 : 0;
+        const unsigned jl2 = 2u * (unsigned)jlane;
+        const bool hi8 = (lane & 8) != 0;
+        int g = wave;
+        int rpv = 0, nrpv = 0;
+        if (g < ngroups) rpv = rp_s[min(8 * g + (lane & 15), n)];
+        for (; g < ngroups; g += nwaves) {
+            if (g + nwaves < ngroups) nrpv = rp_s[min(8 * (g + nwaves) + (lane & 15), n)];
+            int bnd[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) bnd[i] = __builtin_amdgcn_readlane(rpv, i);
+            unsigned raw[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) raw[r] = load_id(cl, 2u * (unsigned)bnd[r] + jl2);   // unconditional (arena slack)
+            const int v = 8 * g + slot;
+            const float4 self = tile[min(v, n) * LPR + sub];       // ahead of the gather (row n = zeros)
+            float4 acc[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int beg = bnd[r], end = bnd[r + 1];
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int e0 = beg; e0 < end; e0 += 64) {
+                    const int cnt = min(64, end - e0);
+                    const unsigned rw = (e0 == beg) ? raw[r] : load_id(cl, 2u * (unsigned)e0 + jl2);
+                    const unsigned valb = (jlane < cnt) ? rw * (FS * 4) : zero_row_b;
+                    {
+                        const f32x4 t0 = lds_read16(bcast8<0>(valb) + subb), t1 = lds_read16(bcast8<1>(valb) + subb),
+                                    t2 = lds_read16(bcast8<2>(valb) + subb), t3 = lds_read16(bcast8<3>(valb) + subb);
+                        acc4(a, (t0 + t1) + (t2 + t3));
+                    }
+                    if (cnt > 32) {                                // wave-uniform: steps 4..7 hold something
+                        const f32x4 t0 = lds_read16(bcast8<4>(valb) + subb), t1 = lds_read16(bcast8<5>(valb) + subb),
+                                    t2 = lds_read16(bcast8<6>(valb) + subb), t3 = lds_read16(bcast8<7>(valb) + subb);
+                        acc4(a, (t0 + t1) + (t2 + t3));
+                    }
+                }
+                acc[r] = a;
+            }
+            // transposing combine: lane bit 5 picks rows {0-3 | 4-7}, bit 4 {r | r+2}, bit 3 {r | r+1}
+            const float4 b0 = swap_add32(acc[0], acc[4]), b1 = swap_add32(acc[1], acc[5]);
+            const float4 b2 = swap_add32(acc[2], acc[6]), b3 = swap_add32(acc[3], acc[7]);
+            const float4 c0 = swap_add16(b0, b2), c1 = swap_add16(b1, b3);
+            const float4 mine = hi8 ? c1 : c0, theirs = hi8 ? c0 : c1;
+            float4 tot;
+            tot.x = mine.x + ror8(theirs.x); tot.y = mine.y + ror8(theirs.y);
+            tot.z = mine.z + ror8(theirs.z); tot.w = mine.w + ror8(theirs.w);
+            if (v < n) {
+                const int beg = bnd_of(rpv, slot), end = bnd_of(rpv, slot + 1);
+                if (p.self_loop) acc4(tot, self);
+                if (!p.backward && p.average) {
+                    const float d = (float)(end - beg + p.self_loop);   // 0/0 -> NaN as in the reference
+                    tot.x /= d; tot.y /= d; tot.z /= d; tot.w /= d;
+                }
+                const int cc = col0 + 4 * sub;
+                if (!p.self_loop) {
+                    float4 sb = self;
+                    if (prescale) {   // the tile holds dp/deg; the (1+eps) term needs dp itself
+                        const float* src = p.x + (size_t)(row0 + v) * p.ldx + cc;
+                        sb.x = (cc + 0 < p.F) ? src[0] : 0.f;
+                        sb.y = (cc + 1 < p.F) ? src[1] : 0.f;
+                        sb.z = (cc + 2 < p.F) ? src[2] : 0.f;
+                        sb.w = (cc + 3 < p.F) ? src[3] : 0.f;
+                    }
+                    tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
+                }
+                float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
+                if (vec_out && cc + 3 < p.F) {
+                    *reinterpret_cast<float4*>(dst) = tot;
+                } else {
+                    if (cc + 0 < p.F) dst[0] = tot.x;
+                    if (cc + 1 < p.F) dst[1] = tot.y;
+                    if (cc + 2 < p.F) dst[2] = tot.z;
+                    if (cc + 3 < p.F) dst[3] = tot.w;
+                }
+            }
+            rpv = nrpv;
+        }
+    } else {
     // y == null: only the d-eps dot product of phase A is wanted.
     // Nothing on the per-row path is a dependent global round trip: the row bounds come from LDS two rows ahead,
     // the row's first 64 column ids are requested one row ahead (unconditional loads: the arena keeps readable
@@ -358,6 +468,8 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
         }
     }
 
+    }   // LPR != 8
+
     if (p.deps_partial) {   // block reduction of the d-eps dot product (fp64, fixed order)
         __syncthreads();    // everyone is done reading the tile; reuse its first bytes
         double* red = reinterpret_cast<double*>(smem);
@@ -424,22 +536,6 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
         acc4(acc, (a12_ + a13_) + (a14_ + a15_));                                                       \
     }
 
-// x' + y' after v_permlane32_swap: lanes 0-31 get x[l] + x[l+32], lanes 32-63 get y[l-32] + y[l]
-__device__ __forceinline__ float swap_add32_1(float x, float y) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float4 swap_add32(const float4 x, const float4 y) {
-    return make_float4(swap_add32_1(x.x, y.x), swap_add32_1(x.y, y.y), swap_add32_1(x.z, y.z), swap_add32_1(x.w, y.w));
-}
-// after v_permlane16_swap: 16-lane rows 0,2 get x[row]+x[row+1], rows 1,3 get y[row-1]+y[row]
-__device__ __forceinline__ float swap_add16_1(float x, float y) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float4 swap_add16(const float4 x, const float4 y) {
-    return make_float4(swap_add16_1(x.x, y.x), swap_add16_1(x.y, y.y), swap_add16_1(x.z, y.z), swap_add16_1(x.w, y.w));
-}
 
 __device__ __forceinline__ float4 sel4(bool c, const float4 a, const float4 b) {
     return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
