@@ -164,7 +164,22 @@ __global__ void __launch_bounds__(256) gnm_disc_du_kernel(const HPtrs hp, int ld
         const float* hl = hp.p[l];
         if (rg < RP) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int r = rg; r < n; r += RP) {
+            int r = rg;
+            for (; r + 3 * RP < n; r += 4 * RP) {          // 4 rows per thread with their loads in flight together
+                float w[4];
+                float4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int v = row0 + r + u * RP;
+                    w[u] = dD[v];
+                    x[u] = *reinterpret_cast<const float4*>(hl + (size_t)v * ldh + 4 * c4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc.x += w[u] * x[u].x; acc.y += w[u] * x[u].y; acc.z += w[u] * x[u].z; acc.w += w[u] * x[u].w;
+                }
+            }
+            for (; r < n; r += RP) {
                 const int v = row0 + r;
                 const float w = dD[v];
                 const float4 x = *reinterpret_cast<const float4*>(hl + (size_t)v * ldh + 4 * c4);
