@@ -21,6 +21,10 @@
 // ---------------------------------------------------------------------------------
 static constexpr int kFinCols = 16;
 
+// workgroup size of the one-workgroup-per-graph kernels: 256 threads when there are plenty of graphs, 1024 when a
+// batch of few large graphs (e.g. 256 x 1000 nodes) would otherwise put 4 waves on each CU
+static inline int per_graph_threads(int B) { return B >= 1024 ? 256 : 1024; }
+
 __device__ __forceinline__ void reduce_partials_slice(const double* partial, int nblk, int H, int c0, double* lds,
                                                       double* tot /*[2*kFinCols]*/) {
     constexpr int NC = 2 * kFinCols;              // columns handled here: 16 of each half
@@ -103,7 +107,7 @@ extern "C" int gnm_bn_finalize(const double* stats_partial, int nblk, int H, lon
 // pooled[b] = sum_{v in graph b} y[v]  (x 1/n_b for "average", graphcnn.py:122-127).
 // One workgroup per graph; a thread owns one 16-B column chunk of every RP-th row.
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gnm_bn_relu_readout_kernel(
+__global__ void __launch_bounds__(1024) gnm_bn_relu_readout_kernel(
     const float* __restrict__ Z, int ldz, const float* __restrict__ scale, const float* __restrict__ shift,
     float* __restrict__ Hout, int ldh, const int32_t* __restrict__ node_off, int H, int relu,
     float* __restrict__ pooled, int ldp, int average) {
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(256) gnm_bn_relu_readout_kernel(
     const int row0 = node_off[b];
     const int n = node_off[b + 1] - row0;
     const int H4 = H >> 2;
-    const int RP = 256 / H4;
+    const int RP = (int)blockDim.x / H4;      // 256 threads, or 1024 when few graphs share the GPU (see the launcher)
     const int tid = threadIdx.x;
     const int rg = tid / H4, c4 = tid - rg * H4;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -152,8 +156,10 @@ extern "C" int gnm_bn_relu_readout(const float* Z, int ldz, const float* scale, 
                                    int average, void* stream) {
     if (B <= 0) return GNM_OK;
     if (H <= 0 || (H & 3) || H > 1024 || (ldz & 3) || (ldh & 3) || (pooled && (ldp & 3))) return GNM_ERR_BAD_ARG;
-    const int H4 = H >> 2, RP = 256 / H4;
-    hipLaunchKernelGGL(gnm_bn_relu_readout_kernel, dim3(B), dim3(256), (size_t)RP * H4 * 16,
+    // one workgroup per graph: with fewer graphs than ~4 per CU, 256-thread workgroups leave the chip idle
+    const int threads = per_graph_threads(B);
+    const int H4 = H >> 2, RP = threads / H4;
+    hipLaunchKernelGGL(gnm_bn_relu_readout_kernel, dim3(B), dim3(threads), (size_t)RP * H4 * 16,
                        reinterpret_cast<hipStream_t>(stream), Z, ldz, scale, shift, Hout, ldh, node_off, H, relu,
                        pooled, ldp, average);
     GNM_CHECK_LAUNCH();
@@ -170,7 +176,7 @@ extern "C" int gnm_bn_relu_readout(const float* Z, int ldz, const float* scale, 
 //                                                           perm[g] < B, graphcnn.py:242 quirk)
 //   g = total * (z*scale+shift > 0);  partial[b] = (sum g, sum g*xhat) per column
 // ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gnm_bn_relu_bwd_stats_kernel(
+__global__ void __launch_bounds__(1024) gnm_bn_relu_bwd_stats_kernel(
     const float* __restrict__ dH, int lddh, const float* __restrict__ dpool, int ldp, int average,
     const float* __restrict__ dsc1, const float* __restrict__ U, int ldu, const int32_t* __restrict__ inv_perm,
     const float* __restrict__ s2sum, const float* __restrict__ Z, int ldz, const float* __restrict__ scale,
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(256) gnm_bn_relu_bwd_stats_kernel(
     const int row0 = node_off[b];
     const int n = node_off[b + 1] - row0;
     const int H4 = H >> 2;
-    const int RP = 256 / H4;
+    const int RP = (int)blockDim.x / H4;
     const int tid = threadIdx.x;
     const int rg = tid / H4, c4 = tid - rg * H4;
     float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
@@ -254,7 +260,7 @@ __global__ void __launch_bounds__(256) gnm_bn_relu_bwd_stats_kernel(
         red[(RP + rg) * H4 + c4] = a2;
     }
     __syncthreads();
-    for (int idx = tid; idx < 2 * H; idx += 256) {
+    for (int idx = tid; idx < 2 * H; idx += (int)blockDim.x) {
         const int which = idx / H, c = idx - which * H;
         const float* base = reinterpret_cast<const float*>(red + (size_t)which * RP * H4);
         double s = 0.0;
@@ -272,8 +278,9 @@ extern "C" int gnm_bn_relu_bwd_stats(const float* dH, int lddh, const float* dpo
     if (H <= 0 || (H & 3) || H > 128 || (ldz & 3) || (ldg & 3) || (dH && (lddh & 3)) || (dpool && (ldp & 3)) ||
         (dsc1 && (ldu & 3)))
         return GNM_ERR_BAD_ARG;
-    const int H4 = H >> 2, RP = 256 / H4;
-    hipLaunchKernelGGL(gnm_bn_relu_bwd_stats_kernel, dim3(B), dim3(256), (size_t)2 * RP * H4 * 16,
+    const int threads = per_graph_threads(B);
+    const int H4 = H >> 2, RP = threads / H4;
+    hipLaunchKernelGGL(gnm_bn_relu_bwd_stats_kernel, dim3(B), dim3(threads), (size_t)2 * RP * H4 * 16,
                        reinterpret_cast<hipStream_t>(stream), dH, lddh, dpool, ldp, average, dsc1, U, ldu, inv_perm,
                        s2sum, Z, ldz, scale, shift, mean, rstd, relu, G, ldg, node_off, B, H, partial);
     GNM_CHECK_LAUNCH();
