@@ -21,7 +21,7 @@ struct HPtrs {
 // wave-instruction when H/4 divides 64, e.g. 4 rows at H = 64); the lane group reduces its
 // dot product with DPP/shuffle steps inside the group.  Generic widths use one wave per row.
 template <int LPR4>   // lanes per row (H/4), a power of two <= 64; 0 = generic
-__global__ void __launch_bounds__(256) gnm_disc_score_kernel(const HPtrs hp, int ldh, int L, int H,
+__global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, int ldh, int L, int H,
                                                              const float* __restrict__ U, int ldu,
                                                              const int32_t* __restrict__ perm_rows,
                                                              const float* __restrict__ bias,
@@ -35,7 +35,8 @@ __global__ void __launch_bounds__(256) gnm_disc_score_kernel(const HPtrs hp, int
     const int n = node_off[g + 1] - row0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int e = tid; e < L * H; e += 256) Us[e] = U[(size_t)g * ldu + e];
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;      // 256 threads, or 1024 for batches of few graphs
+    for (int e = tid; e < L * H; e += nthreads) Us[e] = U[(size_t)g * ldu + e];
     __syncthreads();
     const float bv = bias ? bias[0] : 0.f;
     if (wave == 0) {
@@ -57,7 +58,7 @@ __global__ void __launch_bounds__(256) gnm_disc_score_kernel(const HPtrs hp, int
 #pragma unroll
         for (int l = 0; l < ML; ++l)
             uu[l] = l < L ? *reinterpret_cast<const float4*>(Us + l * H + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = wave * G + slot; r < n + G - 1; r += 4 * G) {   // uniform trip count per wave
+        for (int r = wave * G + slot; r < n + G - 1; r += nwaves * G) {   // uniform trip count per wave
             const int rr = min(r, n - 1);
             const int v = row0 + rr;
             float a = 0.f;
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(256) gnm_disc_score_kernel(const HPtrs hp, int
             }
         }
     } else {
-        for (int r = wave; r < n; r += 4) {
+        for (int r = wave; r < n; r += nwaves) {
             const int v = row0 + r;
             float a = 0.f;
             for (int l = 0; l < L; ++l)
@@ -107,7 +108,7 @@ extern "C" int gnm_disc_score_fwd(const float* const* hptrs, int ldh, int L, int
     const bool vec = ((ldh & 3) == 0) && ((H & 3) == 0);
     const int lpr4 = vec ? H / 4 : 0;
 #define GNM_DISC_CASE(V) \
-    hipLaunchKernelGGL(gnm_disc_score_kernel<V>, dim3(B), dim3(256), lds, st, hp, ldh, L, H, U, ldu, perm_rows, bias, \
+    hipLaunchKernelGGL(gnm_disc_score_kernel<V>, dim3(B), dim3(B >= 1024 ? 256 : 1024), lds, st, hp, ldh, L, H, U, ldu, perm_rows, bias, \
                        node_off, N, d_logit)
     if (lpr4 == 8) GNM_DISC_CASE(8);
     else if (lpr4 == 16) GNM_DISC_CASE(16);
@@ -124,7 +125,7 @@ extern "C" int gnm_disc_score_fwd(const float* const* hptrs, int ldh, int L, int
 // (the gradient wrt n_f itself is folded into gnm_bn_relu_bwd_stats).  Optional by-products for the caller:
 //   dsum[g] = sum_{v in g} (dD[v] + dD[N + v])   (their sum over g is the Bilinear bias gradient)
 //   inv_perm[perm_rows[g]] = g                     (who uses graph g's first-rows as negatives)
-__global__ void __launch_bounds__(256) gnm_disc_du_kernel(const HPtrs hp, int ldh, int L, int H,
+__global__ void __launch_bounds__(1024) gnm_disc_du_kernel(const HPtrs hp, int ldh, int L, int H,
                                                           const float* __restrict__ dD,
                                                           const int32_t* __restrict__ perm_rows,
                                                           const int32_t* __restrict__ node_off, int N,
@@ -133,13 +134,14 @@ __global__ void __launch_bounds__(256) gnm_disc_du_kernel(const HPtrs hp, int ld
                                                           int32_t* __restrict__ inv_perm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* red = reinterpret_cast<float4*>(smem);     // [RP][H4]
-    __shared__ float wsum[8];
+    __shared__ float wsum[32];                          // [2][up to 16 waves]
     const int g = blockIdx.x;
     const int row0 = node_off[g];
     const int n = node_off[g + 1] - row0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = blockDim.x, nwaves = nthreads >> 6;
     float s = 0.f, s1 = 0.f;
-    for (int r = tid; r < n; r += 256) {
+    for (int r = tid; r < n; r += nthreads) {
         s += dD[(size_t)N + row0 + r];
         s1 += dD[(size_t)row0 + r];
     }
@@ -147,17 +149,21 @@ __global__ void __launch_bounds__(256) gnm_disc_du_kernel(const HPtrs hp, int ld
     s1 = wave_sum(s1);
     if (lane == 0) {
         wsum[wave] = s;
-        wsum[4 + wave] = s1;
+        wsum[16 + wave] = s1;
     }
     __syncthreads();
-    const float s2 = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    float s2 = 0.f, s1t = 0.f;
+    for (int w = 0; w < nwaves; ++w) {                  // fixed order
+        s2 += wsum[w];
+        s1t += wsum[16 + w];
+    }
     if (tid == 0) {
         s2sum[g] = s2;
-        if (dsum) dsum[g] = s2 + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]));
+        if (dsum) dsum[g] = s2 + s1t;
         if (inv_perm) inv_perm[perm_rows[g]] = g;
     }
     const int H4 = H >> 2;
-    const int RP = 256 / H4;
+    const int RP = nthreads / H4;
     const int rg = tid / H4, c4 = tid - rg * H4;
     const int pr = perm_rows[g];
     for (int l = 0; l < L; ++l) {
@@ -210,8 +216,9 @@ extern "C" int gnm_disc_score_bwd(const float* const* hptrs, int ldh, int L, int
         return GNM_ERR_BAD_ARG;
     HPtrs hp;
     for (int l = 0; l < GNM_MAX_LAYERS; ++l) hp.p[l] = l < L ? hptrs[l] : nullptr;
-    const int H4 = H >> 2, RP = 256 / H4;
-    hipLaunchKernelGGL(gnm_disc_du_kernel, dim3(B), dim3(256), (size_t)RP * H4 * 16,
+    const int threads = B >= 1024 ? 256 : 1024;       // one workgroup per graph: few graphs -> big workgroups
+    const int H4 = H >> 2, RP = threads / H4;
+    hipLaunchKernelGGL(gnm_disc_du_kernel, dim3(B), dim3(threads), (size_t)RP * H4 * 16,
                        reinterpret_cast<hipStream_t>(stream), hp, ldh, L, H, dD, perm_rows, node_off, N, dU, ldu,
                        s2sum, dsum, inv_perm);
     GNM_CHECK_LAUNCH();
