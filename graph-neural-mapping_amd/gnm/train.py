@@ -162,6 +162,7 @@ class FusedTrainStep:
         self.dp = DataParallelGIN(model, process_group)
         if not self.dp.direct:
             raise RuntimeError("FusedTrainStep needs the sum/average neighbour-pooling model (gradient sink)")
+        self.dp.broadcast_parameters()          # every replica starts from rank 0's parameters and buffers
         self.optimizer = FusedAdam(self.dp.fp, lr, betas, eps, weight_decay)
         self.optimizer.set_grad_scale(1.0 / self.dp.world)
         self.parts = None

@@ -125,3 +125,47 @@ def test_two_ranks_with_sync_bn_equal_one_process_on_the_union_batch(case, tmp_p
     rl = results[False]
     cl = np.concatenate([rl[0]["c_logit"], rl[1]["c_logit"]], 0)
     assert rel_err(cl, c_ref) > 1e-3
+
+
+def _fused_worker(rank, world, port, case, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helpers import load_case
+        from gnm.train import FusedTrainStep
+        cfg, state, d = load_case(case)
+        torch.manual_seed(50 + rank)                      # replicas start different: the step object must sync them
+        model = _model(cfg, state)
+        if rank == 1:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(0.5)
+        step = FusedTrainStep(model, lr=0.01, capture=False)
+        graphs = _graphs(cfg, d)
+        mine = step.dp.shard(graphs)
+        arena = model.arena()
+        batch = arena.batch_from_gids(np.array([arena.add(g) for g in mine], dtype=np.int64))
+        labels = torch.tensor([g.label for g in mine], device=DEV)
+        for s in range(3):
+            step.run(batch, labels, np.arange(len(mine)))
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=step.dp.fp.flat.cpu().numpy(),
+                 grad=step.dp.fp.flat_grad.cpu().numpy(), steps=step.optimizer.step_count.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_train_step_keeps_two_ranks_in_lockstep(tmp_path):
+    """FusedTrainStep over a process group: parameters broadcast from rank 0 at construction, gradients SUM-all-reduced
+    and scaled by 1/world inside the Adam launch -> after three steps both ranks hold bitwise the same parameters."""
+    case = "tiny_s1_eps1_gsum_nsum"
+    mp.spawn(_fused_worker, args=(2, _free_port(), case, str(tmp_path)), nprocs=2, join=True)
+    r = [dict(np.load(tmp_path / f"rank{k}.npz")) for k in range(2)]
+    assert np.array_equal(r[0]["flat"], r[1]["flat"]) and np.array_equal(r[0]["grad"], r[1]["grad"])
+    assert int(r[0]["steps"][0]) == 3 and np.isfinite(r[0]["flat"]).all()
+    from helpers import load_case
+    _, state, _ = load_case(case)
+    moved = np.abs(r[0]["flat"]).sum() != 0 and not np.array_equal(
+        r[0]["flat"][:3], np.asarray(state["eps"], dtype=np.float32)[:3])
+    assert moved                                           # the optimizer did move the parameters
