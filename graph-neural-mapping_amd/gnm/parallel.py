@@ -72,7 +72,6 @@ class DataParallelGIN:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.fp = FlatParams(model)
-        self._avg_ok = None
         # GIN_InfoMaxReg: let the backward kernels write gradients straight into the flat buffer
         # (overwrite semantics: every step produces every gradient, so no zeroing and no
         # AccumulateGrad adds are needed; see GinSpec.grad_sink)
@@ -115,17 +114,6 @@ class DataParallelGIN:
         applied to the union batch)."""
         if self.world == 1:
             return None
-        if not async_op and self._avg_ok is not False and dist.get_backend(self.group) == "nccl":
-            # RCCL averages inside the collective: no separate scaling launch.  Not every build accepts AVG: the
-            # first refusal is remembered and the SUM + scale path below is used from then on.
-            try:
-                dist.all_reduce(self.fp.flat_grad, op=dist.ReduceOp.AVG, group=self.group)
-                self._avg_ok = True
-                return None
-            except Exception:
-                if self._avg_ok:            # it worked before: a real failure, not a missing feature
-                    raise
-                self._avg_ok = False
         work = dist.all_reduce(self.fp.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
             return work
