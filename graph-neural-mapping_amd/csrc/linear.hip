@@ -825,9 +825,14 @@ struct LbArgs {
 
 // NARROW: K < 32 (the first Linear of layer 0, K = F0): one zero-padded 32-column tile, guarded scalar
 // accesses to X / W / dX, which are small next to the [N,H] streams G and Z.
-template <int KT, int HT, bool STATS, bool NARROW = false>
+// SAMEZ (with STATS): the lower BatchNorm's input sZ IS this Linear's input X and its scale/shift ARE the prologue
+// (the second Linear of every MLP) -- the ReLU mask and the BatchNorm sums are then taken from the X values the
+// weight-gradient product already holds in registers: the wgrad contraction index is permuted so that a lane's X
+// rows are its dX accumulator rows, and no second pass over that array is made.
+template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false>
 __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbArgs p) {   // 2 waves/SIMD: <= 256 registers
     static_assert(!NARROW || (KT == 1 && !STATS), "narrow K: one tile, no lower BatchNorm");
+    static_assert(!SAMEZ || STATS, "SAMEZ is a STATS variant");
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
     constexpr int H4 = HP / 4;                    // float4 per dZ row
@@ -850,11 +855,16 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     __syncthreads();
 
     const int c4 = lane % H4, lrow0 = lane / H4;
-    const float4 mu = *reinterpret_cast<const float4*>(p.mean + 4 * c4);
-    const float4 rs = *reinterpret_cast<const float4*>(p.rstd + 4 * c4);
-    const float4 ca = *reinterpret_cast<const float4*>(p.cA + 4 * c4);
-    const float4 a1 = *reinterpret_cast<const float4*>(p.m1 + 4 * c4);
-    const float4 a2 = *reinterpret_cast<const float4*>(p.m2 + 4 * c4);
+    // BatchNorm-backward coefficients of this lane's column chunk: kept in registers for the whole kernel, except in
+    // the SAMEZ variant, which needs those 20 registers across the MFMA phases and re-reads them (L1 hits) per tile
+    float4 mu, rs, ca, a1, a2;
+    if constexpr (!SAMEZ) {
+        mu = *reinterpret_cast<const float4*>(p.mean + 4 * c4);
+        rs = *reinterpret_cast<const float4*>(p.rstd + 4 * c4);
+        ca = *reinterpret_cast<const float4*>(p.cA + 4 * c4);
+        a1 = *reinterpret_cast<const float4*>(p.m1 + 4 * c4);
+        a2 = *reinterpret_cast<const float4*>(p.m2 + 4 * c4);
+    }
     float psc[KT], psh[KT];
 #pragma unroll
     for (int b = 0; b < KT; ++b) {
@@ -876,6 +886,13 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     constexpr int OR = 64 / O4;                   // output rows covered per pass of the store loop
     const int oc4 = lane % O4, orow0 = lane / O4;
     float4 ss1 = make_float4(0.f, 0.f, 0.f, 0.f), ss2 = ss1;
+    float cmu[KT], crs[KT], cs1[KT], cs2[KT];     // SAMEZ: this lane's columns 32b + i of the lower BatchNorm
+#pragma unroll
+    for (int b = 0; b < KT; ++b) {
+        cmu[b] = SAMEZ ? p.s_mean[32 * b + i] : 0.f;
+        crs[b] = SAMEZ ? p.s_rstd[32 * b + i] : 0.f;
+        cs1[b] = 0.f; cs2[b] = 0.f;
+    }
 
     const int ntiles = (p.N + 31) / 32;
     const int nlast = p.N - 1;
@@ -888,6 +905,13 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
             const int grow = min(r0 + lrow0 + j * RSTEP, nlast);
             g4[j] = *reinterpret_cast<const float4*>(p.G + (size_t)grow * p.ldg + 4 * c4);
             z4[j] = *reinterpret_cast<const float4*>(p.Z + (size_t)grow * p.ldz + 4 * c4);
+        }
+        if constexpr (SAMEZ) {
+            mu = *reinterpret_cast<const float4*>(p.mean + 4 * c4);
+            rs = *reinterpret_cast<const float4*>(p.rstd + 4 * c4);
+            ca = *reinterpret_cast<const float4*>(p.cA + 4 * c4);
+            a1 = *reinterpret_cast<const float4*>(p.m1 + 4 * c4);
+            a2 = *reinterpret_cast<const float4*>(p.m2 + 4 * c4);
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- dZ tile -> LDS (rows past N are zero: they must not contribute) ----------
@@ -910,7 +934,10 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
         float xv[16][KT];                         // X[r0 + 2s + h][32b + i]
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int grow = min(r0 + 2 * s + h, nlast);
+            // contraction index of the wgrad product: any order, as long as dZ (below) uses the same one.  SAMEZ takes
+            // the 32x32 accumulator's row order, so that xv[s] sits on the rows of dacc[.][s]
+            const int krow = SAMEZ ? (s & 3) + 8 * (s >> 2) + 4 * h : 2 * s + h;
+            const int grow = min(r0 + krow, nlast);
 #pragma unroll
             for (int b = 0; b < KT; ++b)
                 xv[s][b] = (!NARROW || 32 * b + i < p.K) ? p.X[(size_t)grow * p.ldx + 32 * b + i] : 0.f;
@@ -941,8 +968,10 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             float av[HT];
+            const int krow = SAMEZ ? (s & 3) + 8 * (s >> 2) + 4 * h : 2 * s + h;
 #pragma unroll
-            for (int a = 0; a < HT; ++a) av[a] = Xs[(2 * s + h) * XS + 32 * a + i];
+            for (int a = 0; a < HT; ++a) av[a] = Xs[krow * XS + 32 * a + i];
+            float xf[KT];
 #pragma unroll
             for (int b = 0; b < KT; ++b) {
                 float x = xv[s][b];
@@ -951,20 +980,37 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
                     if (p.pro_relu) x = fmaxf(x, 0.f);
                     if (NARROW && !(32 * b + i < p.K)) x = 0.f;      // padding columns stay zero
                 }
-                xv[s][b] = x;
+                xf[b] = x;                                          // (SAMEZ keeps the raw Z in xv for the epilogue)
             }
 #pragma unroll
             for (int a = 0; a < HT; ++a) {
                 dbacc[a] += av[a];
 #pragma unroll
                 for (int b = 0; b < KT; ++b)
-                    wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], xv[s][b], wacc[a][b], 0, 0, 0);
+                    wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], xf[b], wacc[a][b], 0, 0, 0);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();          // everyone is done reading the dZ image
         // ---- store dX through the staging image (16-B row-contiguous stores) ---------------
         if (p.dA) {
+            if constexpr (SAMEZ) {
+                // ReLU mask of the lower BatchNorm and its backward sums, on the accumulator itself: lane (i, h) holds
+                // column 32c + i of rows (r & 3) + 8 (r >> 2) + 4h, and xv[r][c] is Z of exactly that element
+#pragma unroll
+                for (int c = 0; c < KT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float z = xv[r][c];
+                        float g = dacc[c][r];
+                        if (!(z * psc[c] + psh[c] > 0.f)) g = 0.f;
+                        if (r0 + (r & 3) + 8 * (r >> 2) + 4 * h < p.N) {
+                            cs1[c] += g;
+                            cs2[c] += g * ((z - cmu[c]) * crs[c]);
+                        }
+                        dacc[c][r] = g;
+                    }
+            }
 #pragma unroll
             for (int c = 0; c < KT; ++c)
 #pragma unroll
@@ -972,7 +1018,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if constexpr (STATS) {
+            if constexpr (STATS && !SAMEZ) {
                 __builtin_amdgcn_sched_barrier(0);   // keep these loads below the MFMA phases (register peak)
                 // coefficient vectors are (re)loaded here, not kept across the MFMA phases: they are
                 // L1/L2 hits and 16 registers held for the whole tile would cost a wave of occupancy
@@ -1029,9 +1075,21 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     if constexpr (STATS) {
         __syncthreads();
         double* sred = reinterpret_cast<double*>(smem);           // [4 waves][2][KP]
+        if constexpr (SAMEZ) {
+#pragma unroll
+            for (int c = 0; c < KT; ++c) {                          // the two half-waves hold the same columns
+                double d1 = (double)cs1[c], d2 = (double)cs2[c];
+                d1 += __shfl_xor(d1, 32, 64);
+                d2 += __shfl_xor(d2, 32, 64);
+                if (h == 0) {
+                    sred[(wave * 2 + 0) * KP + 32 * c + i] = d1;
+                    sred[(wave * 2 + 1) * KP + 32 * c + i] = d2;
+                }
+            }
+        }
         float v1[4] = {ss1.x, ss1.y, ss1.z, ss1.w}, v2[4] = {ss2.x, ss2.y, ss2.z, ss2.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < (SAMEZ ? 0 : 4); ++c) {
             double d1 = (double)v1[c], d2 = (double)v2[c];
 #pragma unroll
             for (int off = O4; off < 64; off <<= 1) {
@@ -1089,7 +1147,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     }
 }
 
-template <int KT, int HT, bool STATS, bool NARROW = false>
+template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false>
 static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
@@ -1098,11 +1156,11 @@ static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     if (dump > lds) lds = dump;
     static bool configured = false;
     if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW>),
+        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
         configured = true;
     }
-    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
@@ -1157,7 +1215,12 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     if (KT == 1 && HT == 1) rc = sZ ? launch_lb<1, 1, true>(a, grid, s) : launch_lb<1, 1, false>(a, grid, s);
     if (KT == 2 && HT == 1) rc = sZ ? launch_lb<2, 1, true>(a, grid, s) : launch_lb<2, 1, false>(a, grid, s);
     if (KT == 1 && HT == 2) rc = sZ ? launch_lb<1, 2, true>(a, grid, s) : launch_lb<1, 2, false>(a, grid, s);
-    if (KT == 2 && HT == 2) rc = sZ ? launch_lb<2, 2, true>(a, grid, s) : launch_lb<2, 2, false>(a, grid, s);
+    // the second Linear of an MLP: the lower BatchNorm's input is this Linear's input and its affine is the prologue
+    const bool samez = sZ && sZ == X && ldsz == ldx && s_scale == pro_scale && s_shift == pro_shift && pro_relu &&
+                       !getenv("GNM_LINBWD_NO_SAMEZ");
+    if (KT == 2 && HT == 2)
+        rc = samez ? launch_lb<2, 2, true, false, true>(a, grid, s)
+                   : (sZ ? launch_lb<2, 2, true>(a, grid, s) : launch_lb<2, 2, false>(a, grid, s));
     if (rc != GNM_OK) return rc;
     const long long stride = (long long)H * K + H;
     const int count = H * K + H;

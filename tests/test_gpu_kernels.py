@@ -340,6 +340,30 @@ def test_linear_backward_fused(N, K, H, pro, want_dx):
         assert_close(st[0], Gref.sum(0), rtol=TOL, what="sum g", floor=fl)
         assert_close(st[1], (Gref * xh).sum(0), rtol=TOL, what="sum g*xhat", floor=fl)
         assert_close(dW.cpu().numpy(), dZ.T @ Xe, rtol=TOL, what="dW (stats variant)")
+        if pro:
+            # the shape the model has for the second Linear of an MLP: the lower BatchNorm's input IS X and its affine
+            # IS the prologue -- mask and sums then come from the X registers of the weight-gradient product (K = H =
+            # 64 takes that variant; the others must give the same through the general one)
+            lmu2, lrs2 = X.mean(0).astype(np.float32), (1 / np.sqrt(X.var(0) + 1e-5)).astype(np.float32)
+            lmu2d, lrs2d = t(lmu2), t(lrs2)
+            part2 = torch.full((grid, 2, K), float("nan"), dtype=torch.float64, device=DEV)
+            dA3 = torch.full((N, K), float("nan"), device=DEV)
+            dW3 = torch.full((H, K), float("nan"), device=DEV)
+            check(lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Zd.data_ptr(), H, md.data_ptr(), rd.data_ptr(),
+                                           cd.data_ptr(), m1d.data_ptr(), m2d.data_ptr(), Xd.data_ptr(), K,
+                                           scd.data_ptr(), shd.data_ptr(), 1, Wd.data_ptr(), K, dA3.data_ptr(), K,
+                                           dW3.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, K, H, Xd.data_ptr(), K,
+                                           scd.data_ptr(), shd.data_ptr(), lmu2d.data_ptr(), lrs2d.data_ptr(),
+                                           part2.data_ptr(), _stream()), "linear_bwd_fused + stats (sZ = X)")
+            mask2 = (X * sc + sh) > 0
+            Gref2 = (dZ @ W.astype(f64)) * mask2
+            xh2 = (X.astype(f64) - lmu2) * lrs2
+            assert_close(dA3.cpu().numpy(), Gref2, rtol=TOL, what="masked dX (sZ = X)")
+            st2 = part2.sum(0).cpu().numpy()
+            fl2 = 1e-2 * np.abs(Gref2).sum(0).max()
+            assert_close(st2[0], Gref2.sum(0), rtol=TOL, what="sum g (sZ = X)", floor=fl2)
+            assert_close(st2[1], (Gref2 * xh2).sum(0), rtol=TOL, what="sum g*xhat (sZ = X)", floor=fl2)
+            assert_close(dW3.cpu().numpy(), dZ.T @ Xe, rtol=TOL, what="dW (sZ = X)")
 
 
 @pytest.mark.parametrize("sizes,H", [([40, 40, 40], 64), ([13, 50, 7], 32), ([300, 300], 128), ([1], 64)])
