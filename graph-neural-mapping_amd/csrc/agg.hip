@@ -93,6 +93,13 @@ __device__ __forceinline__ float4 swap_add16(const float4 x, const float4 y) {
 __device__ __forceinline__ float ror8(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
 }
+// x[l ^ 2] / x[l ^ 1] within each quad (DPP quad_perm [2,3,0,1] / [1,0,3,2])
+__device__ __forceinline__ float qxor2(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float qxor1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));
+}
 // lane-indexed read of a lane vector (per-lane index i < 16): v[i] -- two 16-lane-row broadcasts would need a uniform
 // index, so this is a ds_bpermute; used once per 8-row group (degree for "average" only)
 __device__ __forceinline__ int bnd_of(int v, int i) { return __shfl(v, i, 64); }
@@ -354,6 +361,118 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                     tot.x /= d; tot.y /= d; tot.z /= d; tot.w /= d;
                 }
                 const int cc = col0 + 4 * sub;
+                if (!p.self_loop) {
+                    float4 sb = self;
+                    if (prescale) {   // the tile holds dp/deg; the (1+eps) term needs dp itself
+                        const float* src = p.x + (size_t)(row0 + v) * p.ldx + cc;
+                        sb.x = (cc + 0 < p.F) ? src[0] : 0.f;
+                        sb.y = (cc + 1 < p.F) ? src[1] : 0.f;
+                        sb.z = (cc + 2 < p.F) ? src[2] : 0.f;
+                        sb.w = (cc + 3 < p.F) ? src[3] : 0.f;
+                    }
+                    tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
+                }
+                float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
+                if (vec_out && cc + 3 < p.F) {
+                    *reinterpret_cast<float4*>(dst) = tot;
+                } else {
+                    if (cc + 0 < p.F) dst[0] = tot.x;
+                    if (cc + 1 < p.F) dst[1] = tot.y;
+                    if (cc + 2 < p.F) dst[2] = tot.z;
+                    if (cc + 3 < p.F) dst[3] = tot.w;
+                }
+            }
+            rpv = nrpv;
+        }
+    } else if constexpr (LPR == 2) {
+        // ---- 8-float rows (the input layer, F0 <= 8): 2 lanes per neighbour row, 32 neighbours per wave-instruction,
+        // GROUPS OF 16 ROWS per wave.  Lane bit 2 is the 16-B chunk; the other five bits number the 32 neighbour slots,
+        // so both lanes of a slot load the same column id themselves (no cross-lane traffic at all), and the 16 x 32
+        // partial sums are transposed and added over lane bits 5, 4, 3 (permlane swaps, DPP row_ror:8) and 1, 0
+        // (DPP quad_perm): lanes {bit5, bit4, bit3, bit1} = k end up with row k.
+        const int ngroups = p.y ? (n + 15) >> 4 : 0;
+        const int q2 = (lane >> 2) & 1;                                   // chunk of the 32-B row
+        const unsigned p5 = (unsigned)(((lane >> 3) << 2) | (lane & 3));   // neighbour slot 0..31
+        const unsigned sub2b = lds_base + (unsigned)q2 * 16u;
+        const unsigned zero2 = sub2b + (unsigned)n * 32u;
+        const bool b3 = (lane & 8) != 0, b1 = (lane & 2) != 0;
+        const int krow = ((lane >> 3) << 1) | ((lane >> 1) & 1);          // row of the group this lane ends up owning
+        int g = wave;
+        int rpv = 0, nrpv = 0;
+        if (g < ngroups) rpv = rp_s[min(16 * g + (lane & 31), n)];
+        unsigned nr0 = 0, nr1 = 0, nr2 = 0, nr3 = 0;                        // ids of the NEXT row (4 chunks of 32)
+        if (g < ngroups) {
+            const unsigned o = 2u * ((unsigned)__builtin_amdgcn_readlane(rpv, 0) + p5);
+            nr0 = load_id(cl, o); nr1 = load_id(cl, o + 64u); nr2 = load_id(cl, o + 128u); nr3 = load_id(cl, o + 192u);
+        }
+        for (; g < ngroups; g += nwaves) {
+            const bool more = g + nwaves < ngroups;
+            if (more) nrpv = rp_s[min(16 * (g + nwaves) + (lane & 31), n)];
+            const int v = 16 * g + krow;
+            const float4 self = tile[min(v, n) * 2 + q2];
+            float4 acc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int beg = __builtin_amdgcn_readlane(rpv, r), end = __builtin_amdgcn_readlane(rpv, r + 1);
+                const unsigned r0 = nr0, r1 = nr1, r2 = nr2, r3 = nr3;
+                // the next row's ids (row r + 1 of this group, or row 0 of this wave's next group), unconditionally
+                {
+                    const int nb = (r < 15) ? end : __builtin_amdgcn_readlane(nrpv, 0);
+                    if (r < 15 || more) {                              // wave-uniform
+                        const unsigned o = 2u * ((unsigned)nb + p5);
+                        nr0 = load_id(cl, o); nr1 = load_id(cl, o + 64u); nr2 = load_id(cl, o + 128u); nr3 = load_id(cl, o + 192u);
+                    }
+                }
+                const int cnt = end - beg;
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (cnt > 0) {
+                    const unsigned a0 = ((int)p5 < cnt) ? (r0 << 5) + sub2b : zero2;
+                    const unsigned a1 = ((int)p5 + 32 < cnt) ? (r1 << 5) + sub2b : zero2;
+                    if (cnt > 64) {
+                        const unsigned a2 = ((int)p5 + 64 < cnt) ? (r2 << 5) + sub2b : zero2;
+                        const unsigned a3 = ((int)p5 + 96 < cnt) ? (r3 << 5) + sub2b : zero2;
+                        const f32x4 t0 = lds_read16(a0), t1 = lds_read16(a1), t2 = lds_read16(a2), t3 = lds_read16(a3);
+                        acc4(a, (t0 + t1) + (t2 + t3));
+                        for (int e0 = beg + 128; e0 < end; e0 += 32) {       // degree > 128: fetched in place
+                            const unsigned rw = load_id(cl, 2u * ((unsigned)e0 + p5));
+                            const unsigned ax = ((int)p5 < end - e0) ? (rw << 5) + sub2b : zero2;
+                            acc4(a, lds_read16(ax));
+                        }
+                    } else {
+                        const f32x4 t0 = lds_read16(a0), t1 = lds_read16(a1);
+                        acc4(a, t0 + t1);
+                    }
+                }
+                acc[r] = a;
+            }
+            // transposing combine over lane bits 5, 4, 3, 1, then the plain sum over bit 0
+            float4 b8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b8[j] = swap_add32(acc[j], acc[j + 8]);
+            float4 c4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c4[j] = swap_add16(b8[j], b8[j + 4]);
+            float4 d2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 mine = b3 ? c4[j + 2] : c4[j], theirs = b3 ? c4[j] : c4[j + 2];
+                d2[j].x = mine.x + ror8(theirs.x); d2[j].y = mine.y + ror8(theirs.y);
+                d2[j].z = mine.z + ror8(theirs.z); d2[j].w = mine.w + ror8(theirs.w);
+            }
+            const float4 mine = b1 ? d2[1] : d2[0], theirs = b1 ? d2[0] : d2[1];
+            float4 tot;
+            tot.x = mine.x + qxor2(theirs.x); tot.y = mine.y + qxor2(theirs.y);
+            tot.z = mine.z + qxor2(theirs.z); tot.w = mine.w + qxor2(theirs.w);
+            tot.x += qxor1(tot.x); tot.y += qxor1(tot.y); tot.z += qxor1(tot.z); tot.w += qxor1(tot.w);
+            int degk = 0;
+            if (!p.backward && p.average) degk = bnd_of(rpv, krow + 1) - bnd_of(rpv, krow);
+            if (v < n && (lane & 1) == 0) {
+                if (p.self_loop) acc4(tot, self);
+                if (!p.backward && p.average) {
+                    const float d = (float)(degk + p.self_loop);   // 0/0 -> NaN as in the reference
+                    tot.x /= d; tot.y /= d; tot.z /= d; tot.w /= d;
+                }
+                const int cc = col0 + 4 * q2;
                 if (!p.self_loop) {
                     float4 sb = self;
                     if (prescale) {   // the tile holds dp/deg; the (1+eps) term needs dp itself
@@ -994,7 +1113,7 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
     size_t lds = (size_t)(n_max + 1) * LPR * 16;
     const int max_nnz = a.ids_in_lds;             // on entry: largest nnz of the batch (0 = unknown)
     a.ids_in_lds = 0;
-    if (LPR <= 4 && max_nnz > 0 && lds + (size_t)max_nnz * 2 + 96 <= (size_t)kLdsBudget - 1024) {
+    if (LPR == 4 && max_nnz > 0 && lds + (size_t)max_nnz * 2 + 96 <= (size_t)kLdsBudget - 1024) {
         a.ids_in_lds = 1;
         lds += (size_t)max_nnz * 2 + 96;          // + alignment shift and 16-B rounding of the staged id block
     } else {
