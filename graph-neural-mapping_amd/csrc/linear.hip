@@ -760,33 +760,32 @@ extern "C" long long gnm_wgrad_workspace_floats(int N, int H, int K) {
 
 // Second stage: sum the per-block partials in a fixed order and scatter the
 // [H x kw] window into dW (leading dimension ldw, column offset k0) and db.
-// 32 output elements per workgroup, 8 thread groups each summing every 8th partial (so the
+// 32 output elements per workgroup, 32 thread groups each summing every 32nd partial (so the
 // ~8 MB of partials are streamed by ~130 workgroups instead of 17), combined through LDS.
-__global__ void __launch_bounds__(256) gnm_reduce_partials_kernel(const float* __restrict__ partial, int nblk,
-                                                                  long long stride, int H, int kw, int k0,
-                                                                  float* __restrict__ dW, int ldw,
-                                                                  float* __restrict__ db) {
-    __shared__ float red[8][32];
+__global__ void __launch_bounds__(1024) gnm_reduce_partials_kernel(const float* __restrict__ partial, int nblk,
+                                                                   long long stride, int H, int kw, int k0,
+                                                                   float* __restrict__ dW, int ldw,
+                                                                   float* __restrict__ db) {
+    __shared__ float red[32][32];
     const int tid = threadIdx.x;
-    const int grp = tid >> 5;
+    const int grp = tid >> 5, ngrp = (int)blockDim.x >> 5;       // 32 groups of 32 lanes: group g sums partials g, g+32, ...
     const int e = blockIdx.x * 32 + (tid & 31);
     const int count = H * kw + H;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < count) {
         int b = grp;
-        for (; b + 24 < nblk; b += 32) {       // 4 independent loads in flight, fixed summation order
-            const float v0 = partial[(size_t)(b + 0) * stride + e], v1 = partial[(size_t)(b + 8) * stride + e];
-            const float v2 = partial[(size_t)(b + 16) * stride + e], v3 = partial[(size_t)(b + 24) * stride + e];
+        for (; b + 3 * ngrp < nblk; b += 4 * ngrp) {       // 4 independent loads in flight, fixed summation order
+            const float v0 = partial[(size_t)(b + 0 * ngrp) * stride + e], v1 = partial[(size_t)(b + 1 * ngrp) * stride + e];
+            const float v2 = partial[(size_t)(b + 2 * ngrp) * stride + e], v3 = partial[(size_t)(b + 3 * ngrp) * stride + e];
             s0 += v0; s1 += v1; s2 += v2; s3 += v3;
         }
-        for (; b < nblk; b += 8) s0 += partial[(size_t)b * stride + e];
+        for (; b < nblk; b += ngrp) s0 += partial[(size_t)b * stride + e];
     }
     red[grp][tid & 31] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (tid < 32 && e < count) {
         float s = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) s += red[g][tid];
+        for (int g = 0; g < ngrp; ++g) s += red[g][tid];
         if (e < H * kw) {
             const int row = e / kw, col = e - row * kw;
             dW[(size_t)row * ldw + k0 + col] = s;
@@ -1224,7 +1223,7 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     if (rc != GNM_OK) return rc;
     const long long stride = (long long)H * K + H;
     const int count = H * K + H;
-    hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, s, workspace, grid, stride,
+    hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 31) / 32), dim3(1024), 0, s, workspace, grid, stride,
                        H, K, 0, dW, lddw, db);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
@@ -1262,7 +1261,7 @@ extern "C" int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ld
         if (rc != GNM_OK) return rc;
         const long long stride = (long long)H * kw + H;
         const int count = H * kw + H;
-        hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 31) / 32), dim3(256), 0, s, workspace, grid,
+        hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 31) / 32), dim3(1024), 0, s, workspace, grid,
                            stride, H, kw, k0, dW, ldw, db);
         GNM_CHECK_LAUNCH();
     }
