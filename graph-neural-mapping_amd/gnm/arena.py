@@ -8,7 +8,6 @@ a graph-local CSR (int32 rowptr, uint16 columns) and uploaded with its node feat
 a batch is then just B graph ids, from which three small offset vectors are gathered on
 the device.
 """
-import ctypes as C
 
 import numpy as np
 import torch

@@ -4,7 +4,6 @@ mean launch time from HIP events, canonical GB/s and graph-laye
 import argparse
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "graph-neural-mapping_amd"))
