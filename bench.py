@@ -42,14 +42,58 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
+import hashlib
+import socket
+import subprocess
+
 AGG_BYTES_PER_GRAPH_LAYER = lambda n, E, Fw: 4 * n * Fw * 2 + 4 * E + 4 * (n + 1)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 HBM_MEASURED_GBS = 6290.0
 MFMA_F32_PEAK_TF = 157.3
 
 
-def cpu_baseline(graphs, state, budget_s=20.0):
-    """The oracle (kind 'port') on config C1: 32 graphs, fwd + loss + bwd, fp32."""
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves (one process per GPU
+    through torch.distributed.run, rendezvous on 127.0.0.1), relay their output and exit code.  Runs BEFORE this
+    process touches the GPU, and the ranks are children, never an exec over this process."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    return subprocess.call(cmd, env=env)
+
+
+def file_sha256(path):
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def measured_traffic(profile_json, kernel_source, variant):
+    """HBM bytes per 1024-graph launch of the aggregation kernel from the committed PMC summary -- but only while
+    that summary was taken on THIS kernel source (sha256 of csrc/agg.hip recorded by tools/pmc_agg_summary.py);
+    a stale file yields (None, reason): a number that silently stops describing the kernel is worse than none."""
+    if not os.path.exists(profile_json):
+        return None, "no PMC summary (%s)" % os.path.basename(profile_json)
+    tj = json.load(open(profile_json))
+    have = file_sha256(kernel_source)
+    if tj.get("agg_hip_sha256") != have:
+        return None, "stale: %s was measured on agg.hip %s, this is %s" % (
+            os.path.basename(profile_json), str(tj.get("agg_hip_sha256"))[:12], have[:12])
+    ent = tj.get(variant)
+    if not ent:
+        return None, "no '%s' entry in %s" % (variant, os.path.basename(profile_json))
+    return float(ent["hbm_bytes_per_launch"]), ent["source"]
+
+
+def cpu_baseline(graphs, state, budget_s=24.0):
+    """The oracle (kind 'port') on config C1: 32 graphs, fwd + loss + bwd, fp32, both variants SURVEY.md 8(d)
+    asks for: (ii) the full step with the Infomax tail -- `value` -- and (i) encoder + classifier only."""
     from oracle import gin_oracle as O
     try:
         from threadpoolctl import threadpool_info
@@ -60,14 +104,21 @@ def cpu_baseline(graphs, state, budget_s=20.0):
     model = O.OracleGIN(state, 5, 2, True, "sum", "sum", dtype=np.float32)
     rng = np.random.default_rng(0)
     perm = rng.permutation(len(ob))
-    model.train_step_grads(ob, perm, update_running=False)          # warm-up
-    times = []
-    t_end = time.perf_counter() + budget_s
-    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 30):
-        t0 = time.perf_counter()
-        model.train_step_grads(ob, perm, update_running=False)
-        times.append(time.perf_counter() - t0)
+
+    def timed(want_disc, budget):
+        model.train_step_grads(ob, perm, update_running=False, want_disc=want_disc)          # warm-up
+        ts = []
+        t_end = time.perf_counter() + budget
+        while len(ts) < 3 or (time.perf_counter() < t_end and len(ts) < 30):
+            t0 = time.perf_counter()
+            model.train_step_grads(ob, perm, update_running=False, want_disc=want_disc)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    times = timed(True, budget_s * 0.6)
+    times_i = timed(False, budget_s * 0.4)
     med = float(np.median(times))
+    med_i = float(np.median(times_i))
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -77,8 +128,16 @@ def cpu_baseline(graphs, state, budget_s=20.0):
     except Exception:
         pass
     return {"value": len(ob) / med, "unit": "graphs/s", "cores": int(threads), "kind": "port",
-            "sample": "config C1: %d dense-FC 400-node graphs, fwd+loss+bwd, fp32 numpy/scipy oracle, median of %d "
-                      "steps (%.2f s each)" % (len(ob), len(times), med),
+            "sample": "config C1: %d dense-FC 400-node graphs, fwd+loss+bwd WITH the Infomax tail (variant ii), fp32 "
+                      "numpy/scipy oracle, median of %d steps (%.2f s each)" % (len(ob), len(times), med),
+            "encoder_classifier_only": {"value": len(ob) / med_i, "unit": "graphs/s",
+                                        "sample": "variant (i): same graphs, CE(c_logit) only, no discriminator; "
+                                                  "median of %d steps (%.2f s each)" % (len(times_i), med_i)},
+            "what_it_is": "oracle/gin_oracle.py: numpy dense algebra on BLAS threads (`cores` = BLAS thread count) + "
+                          "scipy CSR spmm on ONE thread; its discriminator is two [N,LH]x[LH,LH] GEMMs + row dots, "
+                          "algebraically equal to the reference's nn.Bilinear but without autograd's [N,LH,LH]-sized "
+                          "_trilinear intermediates, so it is FASTER than the reference's own CPU path (7.3 graphs/s "
+                          "on 8 cores in the survey container) -- a reported baseline, not a like-for-like one",
             "host_cpu": cpu, "host_logical_cpus": os.cpu_count()}
 
 
@@ -88,7 +147,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="graphs per GPU per step (default 1024; 512 when --gpus > 1)")
-    ap.add_argument("--pool", type=int, default=None, help="distinct graphs resident per GPU (default = batch)")
+    ap.add_argument("--pool", type=int, default=None,
+                    help="distinct graphs resident per GPU (default 4096 = SURVEY.md 8(d), 390 MB of column ids: more "
+                         "than the 256 MiB Infinity Cache; 512 for the sparse config)")
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="CPU check of the N > 1 launch path: the ranks only rendezvous (gloo), all-reduce one number "
+                         "and rank 0 prints a stub JSON line; no GPU is touched")
     ap.add_argument("--hidden", type=int, default=64)
     ap.add_argument("--layers", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
@@ -117,13 +181,24 @@ def main():
                     help="HIP events around every launch (default: only the two kernels the rooflines are quoted on)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))                 # no launcher around us: be the launcher (nothing touched the GPU yet)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs: python -m torch.distributed.run --nproc-per-node %d bench.py ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.selftest_launch:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"selftest_launch": True, "n_gpus": world, "rank_sum": float(t.item())}))
+        return
     # test hook (1-GPU box): GNM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, which exercises the
     # whole N > 1 code path except RCCL itself
     share = os.environ.get("GNM_BENCH_SHARE_GPU") == "1"
@@ -144,7 +219,7 @@ def main():
 
     sparse = args.config == "c4"
     B = args.batch or ((1024 if world == 1 else 512) if not sparse else 256)
-    pool_n = args.pool or (B if not sparse else 64)
+    pool_n = args.pool or (4096 if not sparse else 512)
     n, f0, H, L, C = (1000 if sparse else 400), 7, (128 if sparse else args.hidden), args.layers, 2
 
     t_gen = time.perf_counter()
@@ -160,7 +235,7 @@ def main():
     dp = DataParallelGIN(model, direct_grads=not args.no_direct_grads, sync_bn=args.sync_bn and world > 1)
     dp.broadcast_parameters()
     arena = model.arena()
-    gids_all = np.array([arena.add(g) for g in pool], dtype=np.int64)
+    gids_all = np.array(arena.add_many(pool), dtype=np.int64)
     labels_all = torch.tensor([g.label for g in pool], dtype=torch.int64, device=dev)
     E = int(pool[0].edge_mat.shape[1])
     t_gen = time.perf_counter() - t_gen
@@ -170,6 +245,7 @@ def main():
     nsteps = args.warmup + args.steps
     batches = []
     for _ in range(nsteps):
+        # main.py:26: a random B-subset of the pool without replacement (with replacement only if the pool is smaller)
         sel = rng.permutation(pool_n)[:B] if pool_n >= B else rng.integers(0, pool_n, B)
         bt = arena.batch_from_gids(gids_all[sel])
         batches.append((bt, labels_all[torch.as_tensor(sel, device=dev)]))
@@ -240,7 +316,7 @@ def main():
     kernel_timer = None
     if not args.no_kernel_timer and captured is None:
         kernel_timer = core.KernelTimer(None if args.time_all_kernels else
-                                        ("agg_fwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
+                                        ("agg_fwd_F%d" % H, "agg_bwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
     # the HIP events of the roofline kernels cost ~2 % of a step when recorded on every launch: they are recorded on
     # every 4th timed step (still inside the timed region, >= 5 steps x 4-9 launches at the default --steps 20)
     timer_every = 1 if args.time_all_kernels or args.steps < 8 else 4
@@ -266,7 +342,7 @@ def main():
     if timer is None and not args.no_kernel_timer and rank == 0:
         # replayed steps carry no HIP events: time the two roofline kernels on a few eager steps of the same
         # batches, after (and outside) the timed region
-        core.TIMER = core.KernelTimer(("agg_fwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
+        core.TIMER = core.KernelTimer(("agg_fwd_F%d" % H, "agg_bwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
         for i in range(min(3, nsteps)):
             bt, lab = batches[i]
             c_logit, d_logit = model.forward_batch(bt, X=feats(bt), perm=perms[i])
@@ -306,30 +382,49 @@ def main():
             summ = timer.summary()
             out["kernel_ms"] = {k: [c, round(ms, 4)] for k, (c, ms, _) in sorted(summ.items())}
             key = "agg_fwd_F%d" % H
-            if key in summ:
-                c, ms, meta = summ[key]
+            # one tag can hold two kernels (KernelTimer.summary keeps them apart as "tag|meta"): quote the roofline on
+            # the variant the step launches most
+            cands = [k for k in summ if k == key or k.startswith(key + "|")]
+            if cands:
+                c, ms, meta = summ[max(cands, key=lambda k: summ[k][0])]
+                fused = bool(meta.get("fused_bnrelu"))
                 bytes_launch = AGG_BYTES_PER_GRAPH_LAYER(n, E, H) * meta["B"]
                 ach = bytes_launch / (ms * 1e-3) / 1e9
-                traffic, traffic_src = None, None
-                tp = os.path.join(ROOT, "profiles", "agg16_traffic.json")
-                if os.path.exists(tp) and H == 64 and n == 400 and default_cfg:
-                    tj = json.load(open(tp))      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_agg.sh)
-                    if meta.get("fused_bnrelu"):  # the launches timed carried the BatchNorm+ReLU+readout prologue
-                        tj = tj["fused_bnrelu"]
-                    # counted on a 1024-graph launch; one workgroup per graph, so it is linear in the graph count
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"] * meta["B"] / 1024.0, tj["source"]
-                roof = {"bound": "hbm", "kernel": "gnm_agg16_kernel (forward, F=%d)" % H, "achieved": ach,
+                # which kernel these launches were (csrc/agg.hip: the 64-wide tile kernel, else feature slices)
+                fs = int(core.lib.gnm_agg_slice_width(H, n))
+                if fs == 64 and H == 64:
+                    kname = "gnm_agg16_kernel (forward, F=64%s)" % (
+                        ", with fused BatchNorm+ReLU+readout prologue" if fused else "")
+                    variant = "fused_bnrelu" if fused else "plain"
+                else:
+                    kname = "gnm_agg_kernel<%d> (forward, F=%d as %d slices of %d floats per graph)" % (
+                        fs // 4, H, (H + fs - 1) // fs, fs)
+                    variant = "sliced_n%d_F%d" % (n, H)
+                traffic, traffic_src = None, "not measured for this configuration"
+                if default_cfg:
+                    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_agg.sh), counted on a 1024-graph
+                    # launch; one workgroup per graph and slice, so it is linear in the graph count
+                    per1024, traffic_src = measured_traffic(os.path.join(ROOT, "profiles", "agg_traffic.json"),
+                                                            os.path.join(PKG, "csrc", "agg.hip"), variant)
+                    if per1024 is not None:
+                        traffic = per1024 * meta["B"] / 1024.0
+                roof = {"bound": "hbm", "kernel": kname, "achieved": ach,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "frac_of_measured_copy_peak": ach / HBM_MEASURED_GBS, "traffic": traffic,
                         "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": bytes_launch, "mean_launch_ms": ms, "launches_timed": c,
                         "graph_layers_per_s": meta["B"] / (ms * 1e-3)}
-                if meta.get("fused_bnrelu"):
+                if fused:
                     # the timed launches also apply the previous layer's BatchNorm+ReLU, write that activation
                     # (4nF bytes per graph, not part of SURVEY 8(d)'s canonical aggregation bytes) and its readout
                     extra = 4.0 * n * H * meta["B"]
-                    roof["kernel"] = "gnm_agg16_kernel (forward, F=%d, with fused BatchNorm+ReLU+readout prologue)" % H
                     roof["frac_incl_fused_activation_write"] = (bytes_launch + extra) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                bkey = "agg_bwd_F%d" % H
+                bc = [k for k in summ if k == bkey or k.startswith(bkey + "|")]
+                if bc:          # the backward launches (same canonical bytes: g in, dh out, same ids)
+                    cb, msb, _ = summ[max(bc, key=lambda k: summ[k][0])]
+                    roof["backward"] = {"mean_launch_ms": msb, "launches_timed": cb,
+                                        "frac": bytes_launch / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS}
             key = "lin_fwd_K%d_H%d" % (H, H)
             if key in summ:
                 c, ms, meta = summ[key]

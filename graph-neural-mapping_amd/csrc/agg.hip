@@ -877,15 +877,27 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         if (acc.x == 12345.678f) p.y[0] = acc.y + acc.z + acc.w;
         return;
     }
-    for (int k0 = 0; wave + k0 * nwaves < ngroups; k0 += 8) {
+    // Row schedule: full rounds deal groups of 4 consecutive rows round-robin (group g -> wave g % nwaves); the
+    // rows left over after the last full round (< 4 * nwaves) are dealt as ONE short group per wave of
+    // floor/ceil(rem / nwaves) rows, so every wave gathers the same number of rows +-1 (n = 400 on 16 waves: 6
+    // groups of 4 + 1 row each; dealing the last 4 groups whole left 12 of 16 waves idle for a seventh of the gather).
+    const int nfull = n / (4 * nwaves);
+    const int tail0 = nfull * 4 * nwaves;
+    const int trem = n - tail0;
+    const int tbase = trem / nwaves, textra = trem - tbase * nwaves;
+    const int tfirst = tail0 + wave * tbase + min(wave, textra);
+    const int trows = tbase + (wave < textra ? 1 : 0);
+    const int ngw = ngroups ? nfull + (trem > 0 ? 1 : 0) : 0;      // groups per wave (the short one may be empty)
+    for (int k0 = 0; k0 < ngw; k0 += 8) {
         int rpv = 0;
         {
-            const int gg = wave + (k0 + (lane >> 3)) * nwaves;
-            const int row = min(4 * gg + min(lane & 7, 4), n);
-            if (gg < ngroups) rpv = rp_s[row];
+            const int gi = k0 + (lane >> 3);
+            const bool full = gi < nfull;
+            const int first = full ? 4 * (wave + gi * nwaves) : tfirst;
+            const int row = min(first + min(lane & 7, full ? 4 : trows), n);
+            if (gi < ngw) rpv = rp_s[row];
         }
-        int ng = (ngroups - wave - k0 * nwaves + nwaves - 1) / nwaves;    // groups of this wave in this block
-        ng = min(ng, 8);
+        const int ng = min(ngw - k0, 8);                                  // groups of this wave in this block
         int nbeg = __builtin_amdgcn_readlane(rpv, 0), nend = __builtin_amdgcn_readlane(rpv, 1);
         // Column ids are prefetched one row ahead as RAW values and only turned into LDS
         // addresses when the row becomes current, so the wait is a counted vmcnt at the use.
@@ -894,10 +906,11 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         const unsigned jl2 = 2u * (unsigned)jlane;
         unsigned nra = load_id(cl, 2u * (unsigned)nbeg + jl2), nrb = load_id(cl, 2u * (unsigned)nbeg + 128u + jl2);
         for (int kk = 0; kk < ng; ++kk) {
-            const int g = wave + (k0 + kk) * nwaves;
+            const bool gfull = k0 + kk < nfull;                                // wave-uniform
+            const int grows = gfull ? 4 : trows;                               // rows of this group (quarter q owns row q)
             // this quarter's own row (for the self term): read it NOW, ahead of the gather, so it
             // is not a dependent LDS round trip behind ~256 queued reads in the epilogue
-            const int v = 4 * g + q;
+            const int v = (gfull ? 4 * (wave + (k0 + kk) * nwaves) : tfirst) + q;
             const float4 self = tile[min(v, n) * LPR + sub];
             float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
             float dsc_v = 0.f;
@@ -986,7 +999,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
 
             if (dbg & 2) {
                 if (tot.x == 12345.678f) p.y[0] = tot.y + tot.z + tot.w + self.x;   // keep values live
-            } else if (v < n) {
+            } else if (q < grows) {
                 if (p.self_loop) acc4(tot, self);
                 if (!p.backward && p.average) {
                     const float d = (float)(degv + p.self_loop);   // 0/0 -> NaN as in the reference
@@ -1084,21 +1097,13 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
 static int launch_agg16(const AggArgs& a, int B, int n_max, hipStream_t stream) {
     size_t lds = (size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 16;
     if (a.p_scale) lds += 16 + (size_t)1024 * 16;     // forward prologue: readout partials of up to 1024 threads
-    static bool configured = false;
-    if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg16_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg16_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        configured = true;
-    }
+    GNM_ALLOW_FULL_LDS(&gnm_agg16_kernel<false>);
+    GNM_ALLOW_FULL_LDS(&gnm_agg16_kernel<true>);
     int threads = 1024;
     if (lds <= 20 * 1024) threads = 256;
     else if (lds <= 48 * 1024) threads = 512;
-    if (const char* e = getenv("GNM_AGG16_THREADS")) {   // tuning knob for tools/bench_agg.py
-        const int t = atoi(e);
-        if (t >= 64 && t <= 1024 && (t & 63) == 0) threads = t;
-    }
+    static const int env_threads = gnm_env_int("GNM_AGG16_THREADS", 0);   // tuning knob for tools/bench_agg.py
+    if (env_threads >= 64 && env_threads <= 1024 && (env_threads & 63) == 0) threads = env_threads;
     if (a.sZ)
         hipLaunchKernelGGL(gnm_agg16_kernel<true>, dim3(B * a.nslices), dim3(threads), lds, stream, a);
     else
@@ -1119,12 +1124,7 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
     } else {
         lds += (size_t)(n_max + 2) * 4 + 16;       // staged row offsets (gnm_agg_slice_width budgets for them)
     }
-    static size_t configured = 0;
-    if (lds > configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_agg_kernel<LPR>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        configured = kLdsBudget;
-    }
+    GNM_ALLOW_FULL_LDS(&gnm_agg_kernel<LPR>);
     // one workgroup per CU when the tile is large (16 waves to keep the LDS pipe busy);
     // smaller tiles share a CU, so use fewer waves per workgroup.
     int threads = 1024;
@@ -1169,7 +1169,8 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
     a.average = average; a.self_loop = self_loop; a.backward = backward;
     a.debug = 0;
     a.ids_in_lds = nnz_max > 0 ? nnz_max : 0;   // launch_agg turns this into the 0/1 flag
-    if (const char* e = getenv("GNM_AGG16_DEBUG")) a.debug = atoi(e);
+    static const int env_debug = gnm_env_int("GNM_AGG16_DEBUG", 0);   // only acted on by -DGNM_AGG16_TUNING builds
+    a.debug = env_debug;
     if (deps_partial && !hfwd) return GNM_ERR_BAD_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (fs) {

@@ -19,6 +19,29 @@
         if (e__ != hipSuccess) return (int)e__;     \
     } while (0)
 
+// ---- host-side launch helpers ------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): a process that
+// drives several GPUs must set it on each of them.  One DeviceOnce per kernel instantiation keeps
+// a flag per device ordinal (thread-safe; a racing second setter only repeats an idempotent call).
+#include "gnm_once.h"
+#define GNM_ALLOW_FULL_LDS(kernel_ptr)                                                               \
+    do {                                                                                             \
+        static GnmDeviceOnce once__;                                                                 \
+        int dev__ = 0;                                                                               \
+        GNM_HIP(hipGetDevice(&dev__));                                                               \
+        if (once__.first_use(dev__)) {                                                               \
+            GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel_ptr),                   \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); \
+            once__.mark(dev__);                                                                      \
+        }                                                                                            \
+    } while (0)
+
+// Tuning knobs are read from the environment ONCE per process (function-local statics at the call sites).
+static inline int gnm_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 

@@ -9,9 +9,24 @@
 #include <algorithm>
 #include <vector>
 
+#include "gnm_once.h"
+
 extern "C" {
 
-const char* gnm_version(void) { return "gnm_hip 0.1 (gfx950)"; }
+const char* gnm_version(void) { return "gnm_hip 0.2 (gfx950)"; }
+
+// Test hook for the per-device launch-configuration guard (GnmDeviceOnce, the object behind
+// GNM_ALLOW_FULL_LDS): behaves exactly like one kernel's guard, on a private instance and without
+// touching any device.  Returns 1 when `device` had not been configured yet (and marks it), else 0;
+// reset != 0 forgets every device first.
+int gnm_debug_device_once(int device, int reset) {
+    static GnmDeviceOnce once;
+    if (reset)
+        for (int d = 0; d < kGnmMaxDevices; ++d) once.done[d].store(0);
+    if (!once.first_use(device)) return 0;
+    once.mark(device);
+    return 1;
+}
 
 // rowptr[n+1], col[E]: row = edge_mat[0][e], col = edge_mat[1][e]; edges of a row keep
 // their edge_mat order (stable counting sort); duplicates are kept (COO duplicates add).
@@ -41,20 +56,17 @@ int gnm_csr_transpose(const int32_t* rowptr, const uint16_t* col, int n, int32_t
     return 0;
 }
 
-// 1 when A and A^T hold the same edge multiset (then the backward may gather over A itself)
+// 1 when A and A^T hold the same edge multiset (then the backward may gather over A itself).
+// Two counting-sort transposes, O(n + E): T1 = A^T and T2 = T1^T = A both come out with sorted rows, so A is
+// symmetric exactly when the two canonical forms are equal (round 1 sorted every row: 1/3 of the 9 ms first touch).
 int gnm_csr_is_symmetric(const int32_t* rowptr, const uint16_t* col, int n) {
     const int32_t E = rowptr[n];
-    std::vector<int32_t> rpt(n + 1);
-    std::vector<uint16_t> ct(E > 0 ? E : 1);
-    gnm_csr_transpose(rowptr, col, n, rpt.data(), ct.data());
-    if (memcmp(rpt.data(), rowptr, sizeof(int32_t) * (n + 1)) != 0) return 0;
-    std::vector<uint16_t> row;
-    for (int r = 0; r < n; ++r) {
-        row.assign(col + rowptr[r], col + rowptr[r + 1]);
-        std::sort(row.begin(), row.end());
-        if (!std::equal(row.begin(), row.end(), ct.begin() + rowptr[r])) return 0;   // A^T rows come out sorted
-    }
-    return 1;
+    std::vector<int32_t> rp1(n + 1), rp2(n + 1);
+    std::vector<uint16_t> c1(E > 0 ? E : 1), c2(E > 0 ? E : 1);
+    gnm_csr_transpose(rowptr, col, n, rp1.data(), c1.data());
+    if (memcmp(rp1.data(), rowptr, sizeof(int32_t) * (n + 1)) != 0) return 0;     // in-degrees != out-degrees
+    gnm_csr_transpose(rp1.data(), c1.data(), n, rp2.data(), c2.data());
+    return memcmp(c1.data(), c2.data(), sizeof(uint16_t) * (size_t)E) == 0 ? 1 : 0;
 }
 
 // Expand a batch of per-graph CSRs to the reference's block-diagonal COO index

@@ -18,7 +18,10 @@
 //     in the 32x32 C/D layout a lane owns one output COLUMN, so the statistics are
 //     register adds.
 #include "gnm_common.h"
-#include <stdlib.h>
+
+// tuning knobs, read once per process
+static bool lin_force_generic() { static const bool v = getenv("GNM_LIN_GENERIC") != nullptr; return v; }
+static bool linbwd_no_samez() { static const bool v = getenv("GNM_LINBWD_NO_SAMEZ") != nullptr; return v; }
 
 struct LinArgs {
     const float* X;
@@ -377,12 +380,7 @@ static int launch_lin_fast(const LinArgs& a, int grid, hipStream_t s) {
     const size_t red = (size_t)4 * 2 * HP * 8;
     if (red > lds) lds = red;
     if (lds > (size_t)kLdsBudget) return GNM_ERR_UNSUPPORTED;
-    static bool configured = false;
-    if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_lin_fast_kernel<KC, HT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        configured = true;
-    }
+    GNM_ALLOW_FULL_LDS((&gnm_lin_fast_kernel<KC, HT>));
     hipLaunchKernelGGL((gnm_lin_fast_kernel<KC, HT>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
@@ -399,22 +397,27 @@ template <int KC, int HT>
 static int launch_lin(const LinArgs& a, int grid, hipStream_t s) {
     const size_t lds = lin_lds_bytes(a.K, KC, HT);
     if (lds > (size_t)kLdsBudget) return GNM_ERR_UNSUPPORTED;
-    static bool configured = false;
-    if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_lin_kernel<KC, HT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        configured = true;
-    }
+    GNM_ALLOW_FULL_LDS((&gnm_lin_kernel<KC, HT>));
     hipLaunchKernelGGL((gnm_lin_kernel<KC, HT>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
+}
+
+// Largest input width K that gnm_linear_fwd accepts for output width H (the weight [K x H] stays in LDS for the
+// kernel's lifetime): what a caller checks before building a model around it.  0 when H itself is unsupported.
+extern "C" int gnm_linear_max_k(int H) {
+    if (H <= 0 || H > 128) return 0;
+    const int HT = (H + 31) / 32;
+    int k = 0;
+    while (lin_lds_bytes(k + 64, 64, HT) <= (size_t)kLdsBudget) k += 64;
+    return k;
 }
 
 // Blocks gnm_linear_fwd launches for N rows (= rows of stats_partial it writes).
 extern "C" int gnm_linear_grid(int N) {
     const int ntiles = (N + 31) / 32;
     int g = (ntiles + 3) / 4;
-    static const int cap = getenv("GNM_LIN_GRID") ? atoi(getenv("GNM_LIN_GRID")) : 768;   // tuning knob
+    static const int cap = gnm_env_int("GNM_LIN_GRID", 768);   // tuning knob
     if (g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
@@ -438,7 +441,7 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
     const bool aligned = ((ldx & 3) == 0) && ((ldz & 3) == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(Z) & 15) == 0) &&
                          (!pro_scale || (((reinterpret_cast<uintptr_t>(pro_scale) | reinterpret_cast<uintptr_t>(pro_shift)) & 15) == 0));
-    if (aligned && (H % 32) == 0 && (K % 32) == 0 && !getenv("GNM_LIN_GENERIC")) {
+    if (aligned && (H % 32) == 0 && (K % 32) == 0 && !lin_force_generic()) {
         const int kcf = (K % 64) == 0 ? 64 : 32;
         int rc = GNM_ERR_UNSUPPORTED;
 #define GNM_LINF_CASE(KC_, HT_) if (kcf == KC_ && HT == HT_) rc = launch_lin_fast<KC_, HT_>(a, grid, s);
@@ -721,12 +724,7 @@ __global__ void __launch_bounds__(256) gnm_wgrad_fast_kernel(const WgArgs p) {
 template <int WI, int WJ, int QI, int QJ>
 static int launch_wgrad_fast(const WgArgs& a, int grid, hipStream_t s) {
     const size_t lds = ((size_t)4 * WI * WJ * 1024 + (size_t)4 * WI * 64) * 4;
-    static bool configured = false;
-    if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_wgrad_fast_kernel<WI, WJ, QI, QJ>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        configured = true;
-    }
+    GNM_ALLOW_FULL_LDS((&gnm_wgrad_fast_kernel<WI, WJ, QI, QJ>));
     hipLaunchKernelGGL((gnm_wgrad_fast_kernel<WI, WJ, QI, QJ>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
@@ -735,12 +733,7 @@ static int launch_wgrad_fast(const WgArgs& a, int grid, hipStream_t s) {
 template <int WI, int WJ, int QI, int QJ>
 static int launch_wgrad(const WgArgs& a, int grid, hipStream_t s) {
     const size_t lds = ((size_t)4 * WI * WJ * 1024 + (size_t)4 * WI * 64) * 4;
-    static bool configured = false;
-    if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_wgrad_kernel<WI, WJ, QI, QJ>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        configured = true;
-    }
+    GNM_ALLOW_FULL_LDS((&gnm_wgrad_kernel<WI, WJ, QI, QJ>));
     hipLaunchKernelGGL((gnm_wgrad_kernel<WI, WJ, QI, QJ>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
@@ -1153,12 +1146,7 @@ static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     size_t lds = (size_t)HP * KP * 4 + (size_t)4 * 32 * XS * 4;
     const size_t dump = ((size_t)4 * HT * KT * 1024 + (size_t)4 * HT * 64) * 4;
     if (dump > lds) lds = dump;
-    static bool configured = false;
-    if (!configured) {
-        GNM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-        configured = true;
-    }
+    GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ>));
     hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
@@ -1166,7 +1154,7 @@ static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
 
 extern "C" int gnm_linear_bwd_grid(int N) {
     int g = ((N + 31) / 32 + 3) / 4;
-    static const int cap = getenv("GNM_LINBWD_GRID") ? atoi(getenv("GNM_LINBWD_GRID")) : 512;   // tuning knob
+    static const int cap = gnm_env_int("GNM_LINBWD_GRID", 512);   // tuning knob
     if (g > cap) g = cap;
     return g < 1 ? 1 : g;
 }
@@ -1186,7 +1174,7 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     if (N <= 0) return GNM_ERR_UNSUPPORTED;
     const bool narrow = K >= 1 && K < 32 && !sZ;            // zero-padded single K tile, scalar X / dX accesses
     if ((K != 32 && K != 64 && !narrow) || (H != 32 && H != 64)) return GNM_ERR_UNSUPPORTED;
-    if ((ldg & 3) || (ldz & 3) || (dA && !narrow && (lda & 3)) || getenv("GNM_LIN_GENERIC")) return GNM_ERR_UNSUPPORTED;
+    if ((ldg & 3) || (ldz & 3) || (dA && !narrow && (lda & 3)) || lin_force_generic()) return GNM_ERR_UNSUPPORTED;
     const uintptr_t al = reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Z) |
                          (narrow ? 0 : reinterpret_cast<uintptr_t>(dA)) | reinterpret_cast<uintptr_t>(mean) |
                          reinterpret_cast<uintptr_t>(rstd) | reinterpret_cast<uintptr_t>(cA) |
@@ -1216,7 +1204,7 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     if (KT == 1 && HT == 2) rc = sZ ? launch_lb<1, 2, true>(a, grid, s) : launch_lb<1, 2, false>(a, grid, s);
     // the second Linear of an MLP: the lower BatchNorm's input is this Linear's input and its affine is the prologue
     const bool samez = sZ && sZ == X && ldsz == ldx && s_scale == pro_scale && s_shift == pro_shift && pro_relu &&
-                       !getenv("GNM_LINBWD_NO_SAMEZ");
+                       !linbwd_no_samez();
     if (KT == 2 && HT == 2)
         rc = samez ? launch_lb<2, 2, true, false, true>(a, grid, s)
                    : (sZ ? launch_lb<2, 2, true>(a, grid, s) : launch_lb<2, 2, false>(a, grid, s));
@@ -1250,7 +1238,7 @@ extern "C" int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ld
         const int WI = HT < 2 ? HT : 2, WJ = KT < 2 ? KT : 2;
         const int QI = (HT + WI - 1) / WI, QJ = (KT + WJ - 1) / WJ;
         int rc = GNM_ERR_UNSUPPORTED;
-        const bool fast = (H % 32) == 0 && N > 0 && !getenv("GNM_LIN_GENERIC");
+        const bool fast = (H % 32) == 0 && N > 0 && !lin_force_generic();
 #define GNM_WG_CASE(WI_, WJ_, QI_, QJ_)                                                       \
     if (WI == WI_ && WJ == WJ_ && QI == QI_ && QJ == QJ_)                                     \
         rc = fast ? launch_wgrad_fast<WI_, WJ_, QI_, QJ_>(a, grid, s) : launch_wgrad<WI_, WJ_, QI_, QJ_>(a, grid, s);

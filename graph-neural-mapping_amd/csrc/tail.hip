@@ -64,8 +64,10 @@ __global__ void __launch_bounds__(256) gnm_loss_finish_kernel(const float* __res
         float se = 0.f;
         for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
         const float lse = mx + logf(se);
-        const int lab = (int)labels[r];
-        ce += (double)(lse - row[lab]);
+        const long long labl = labels[r];
+        const bool lab_ok = labl >= 0 && labl < C;     // torch's CrossEntropyLoss asserts on the device; here an
+        const int lab = lab_ok ? (int)labl : 0;        // out-of-range label reads nothing and makes the loss NaN
+        ce += lab_ok ? (double)(lse - row[lab]) : (double)__builtin_nanf("");
         if (dC) {
             const float inv = 1.f / se;
             for (int c = 0; c < C; ++c)

@@ -14,6 +14,7 @@ _i, _ll, _f, _p = C.c_int, C.c_longlong, C.c_float, C.c_void_p
 # name -> (restype, [argtypes]); order and meaning exactly as in include/gnm_hip.h
 SIGNATURES = {
     "gnm_version": (C.c_char_p, []),
+    "gnm_debug_device_once": (_i, [_i, _i]),
     "gnm_csr_from_edge_mat": (_i, [_p, _ll, _i, _p, _p]),
     "gnm_csr_transpose": (_i, [_p, _p, _i, _p, _p]),
     "gnm_csr_is_symmetric": (_i, [_p, _p, _i]),
@@ -30,6 +31,7 @@ SIGNATURES = {
     "gnm_rowdot_partials": (_i, [_p, _i, _p, _i, _ll, _i, _p, _p]),
     "gnm_sum_partials_multi": (_i, [_p, _ll, _p, _i, _p, _p]),
     "gnm_linear_grid": (_i, [_i]),
+    "gnm_linear_max_k": (_i, [_i]),
     "gnm_linear_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),
     "gnm_wgrad_grid": (_i, [_i]),
     "gnm_wgrad_workspace_floats": (_ll, [_i, _i, _i]),
@@ -74,7 +76,10 @@ def _load():
     if os.path.exists(tl):
         C.CDLL(tl, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(path)
+    variant = bool(os.environ.get("GNM_HIP_LIB"))    # an A/B build of an older commit may predate a symbol
     for name, (res, args) in SIGNATURES.items():
+        if variant and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args

@@ -90,7 +90,10 @@ class GraphArena:
             pass
         return gid
 
-    def add_raw(self, n, edge_mat, feats):
+    @staticmethod
+    def _host_csr(n, edge_mat):
+        """(rowptr int32 [n+1], col uint16 [E], transposed pair or None) of one graph, on the host (C calls that
+        release the GIL)."""
         E = edge_mat.shape[1]
         rowptr = np.empty(n + 1, dtype=np.int32)
         col = np.empty(max(E, 1), dtype=np.uint16)
@@ -98,27 +101,95 @@ class GraphArena:
               "gnm_csr_from_edge_mat")
         col = col[:E]
         sym = bool(lib.gnm_csr_is_symmetric(rowptr.ctypes.data, col.ctypes.data if E else None, n)) if E else True
-        rp_off = self.rowptr.append(torch.from_numpy(rowptr))
-        col_off = self.col.append(torch.from_numpy(col.view(np.int16)))
-        if sym:
-            t_rp_off, t_col_off = rp_off, col_off
-        else:
+        tr = None
+        if not sym:
             rpt = np.empty(n + 1, dtype=np.int32)
             ct = np.empty(max(E, 1), dtype=np.uint16)
             check(lib.gnm_csr_transpose(rowptr.ctypes.data, col.ctypes.data, n, rpt.ctypes.data, ct.ctypes.data),
                   "gnm_csr_transpose")
-            t_rp_off = self.rowptr.append(torch.from_numpy(rpt))
-            t_col_off = self.col.append(torch.from_numpy(ct[:E].view(np.int16)))
+            tr = (rpt, ct[:E])
+        return rowptr, col, tr
+
+    def add_raw(self, n, edge_mat, feats):
+        return self._append_host([(n, self._host_csr(n, edge_mat), feats)])[0]
+
+    def _append_host(self, items):
+        """items: [(n, (rowptr, col, transposed or None), feats)].  ONE upload per array for the whole list
+        (round 1 made three synchronous copies per graph); returns the new arena ids."""
+        if not items:
+            return []
+        rps, cols, fts = [], [], []
+        rp_pos, col_pos, feat_pos = self.rowptr.size, self.col.size, (self.feat.size if self.feat is not None else 0)
+        F0 = items[0][2].shape[1] if self.feat is None else self.feat.width
+        meta = []
+        for n, (rowptr, col, tr), feats in items:
+            if tuple(feats.shape) != (n, F0):
+                raise ValueError("node_features must be [n, %d], got %s" % (F0, tuple(feats.shape)))
+            E = int(col.shape[0])
+            rp_off, col_off = rp_pos, col_pos
+            rps.append(rowptr); cols.append(col)
+            rp_pos += n + 1; col_pos += E
+            if tr is None:
+                t_rp_off, t_col_off = rp_off, col_off
+            else:
+                t_rp_off, t_col_off = rp_pos, col_pos
+                rps.append(tr[0]); cols.append(tr[1])
+                rp_pos += n + 1; col_pos += E
+            fts.append(feats)
+            meta.append((n, E, tr is None, rp_off, col_off, t_rp_off, t_col_off, feat_pos))
+            feat_pos += n
         if self.feat is None:
-            self.feat = _Growable(torch.float32, self.device, width=feats.shape[1])
-        if feats.shape != (n, self.feat.width):
-            raise ValueError("node_features must be [n, %d], got %s" % (self.feat.width, tuple(feats.shape)))
-        feat_off = self.feat.append(feats)
-        self.n.append(n); self.nnz.append(E); self.sym.append(sym)
-        self.rp_off.append(rp_off); self.col_off.append(col_off)
-        self.t_rp_off.append(t_rp_off); self.t_col_off.append(t_col_off); self.feat_off.append(feat_off)
+            self.feat = _Growable(torch.float32, self.device, width=F0)
+        off = self.rowptr.append(torch.from_numpy(np.concatenate(rps)))
+        assert off == meta[0][3]
+        self.col.append(torch.from_numpy(np.concatenate(cols).view(np.int16)))
+        self.feat.append(torch.cat(fts, 0) if len(fts) > 1 else fts[0])
+        first = len(self.n)
+        for n, E, sym, rp_off, col_off, t_rp_off, t_col_off, feat_off in meta:
+            self.n.append(n); self.nnz.append(E); self.sym.append(sym)
+            self.rp_off.append(rp_off); self.col_off.append(col_off)
+            self.t_rp_off.append(t_rp_off); self.t_col_off.append(t_col_off); self.feat_off.append(feat_off)
         self._dev_tables = None
-        return len(self.n) - 1
+        return list(range(first, len(self.n)))
+
+    def add_many(self, graphs, threads=None):
+        """add() for a whole dataset: host CSRs built on a few threads, one upload per array.  Returns the arena
+        ids in order (graphs already in the arena keep theirs)."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        ids = [None] * len(graphs)
+        todo = []
+        for i, g in enumerate(graphs):
+            cached = getattr(g, "_gnm_cache", None)
+            if cached is not None and cached[0] is self._token:
+                ids[i] = cached[1]
+            else:
+                todo.append(i)
+
+        def prep(i):
+            g = graphs[i]
+            n = len(g.g)
+            em = g.edge_mat
+            em = em.detach().cpu().numpy() if torch.is_tensor(em) else np.asarray(em)
+            em = np.ascontiguousarray(em, dtype=np.int64).reshape(2, -1)
+            feats = g.node_features
+            feats = feats.detach().cpu() if torch.is_tensor(feats) else torch.as_tensor(np.asarray(feats))
+            return n, self._host_csr(n, em), feats.to(torch.float32).contiguous()
+
+        threads = threads or min(16, os.cpu_count() or 1)
+        if len(todo) >= 32 and threads > 1:
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                items = list(ex.map(prep, todo))
+        else:
+            items = [prep(i) for i in todo]
+        new = self._append_host(items)
+        for i, gid in zip(todo, new):
+            ids[i] = gid
+            try:
+                graphs[i]._gnm_cache = (self._token, gid)
+            except Exception:
+                pass
+        return ids
 
     def _tables(self):
         if self._dev_tables is None:
@@ -134,7 +205,7 @@ class GraphArena:
 
     # ------------------------------------------------------------------ batches
     def batch(self, graphs):
-        gids = [self.add(g) for g in graphs]
+        gids = self.add_many(graphs)
         return self.batch_from_gids(torch.tensor(gids, dtype=torch.int64))
 
     def batch_from_gids(self, gids):

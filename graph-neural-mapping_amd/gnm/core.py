@@ -29,18 +29,46 @@ def _stream():
     return _STREAM if _STREAM is not None else torch.cuda.current_stream().cuda_stream
 
 
+def launch_device(*tensors):
+    """The one CUDA device all of `tensors` (None entries skipped) live on; GnmError otherwise.  The kernels
+    take raw pointers, so nothing below this check would notice a CPU tensor or a second device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GnmError("the GIN hot path runs on the GPU only (libgnm_hip.so); got a %s tensor" % t.device)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise GnmError("tensors on different devices (%s and %s): one model replica lives on one GPU"
+                           % (dev, t.device))
+    if dev is None:
+        raise GnmError("no device tensor to launch on")
+    return dev
+
+
 class _stream_scope:
-    """torch.cuda.current_stream() costs ~10 us of Python per call and there are ~110
-    launches per step: resolve it once for the duration of a forward or backward."""
+    """Makes `device` (the device of the tensors being worked on, NOT whatever torch.cuda.current_device() happens
+    to be) current for the duration of a forward or backward, and resolves its current stream once:
+    torch.cuda.current_stream() costs ~10 us of Python per call and there are ~110 launches per step.  Without
+    the device switch a model built on cuda:1 in a process whose current device is 0 would launch on device 0's
+    stream with device-1 pointers (autograd's backward thread sets the device, a custom Function.forward does not)."""
+
+    def __init__(self, device):
+        self.device = device
 
     def __enter__(self):
         global _STREAM
         self.prev = _STREAM
-        _STREAM = torch.cuda.current_stream().cuda_stream
+        self.guard = torch.cuda.device(self.device)
+        self.guard.__enter__()
+        _STREAM = torch.cuda.current_stream(self.device).cuda_stream
 
     def __exit__(self, *exc):
         global _STREAM
         _STREAM = self.prev
+        self.guard.__exit__(*exc)
         return False
 
 
@@ -54,15 +82,36 @@ class KernelTimer:
         self.prefixes = tuple(prefixes) if prefixes else None   # only time launches whose tag starts with one
 
     def summary(self):
-        """name -> (count, mean ms, meta of the first record); call after a synchronize."""
-        out = {}
+        """name -> (count, mean ms, meta); call after a synchronize.  Launches recorded under one name with
+        DIFFERENT meta (e.g. the fused-prologue aggregation and the plain one) are different kernels: they are
+        kept apart under "name|key=value,..." of the differing keys, never averaged together."""
+        groups = {}
         for name, meta, a, b in self.records:
-            c, t, m = out.get(name, (0, 0.0, meta))
-            out[name] = (c + 1, t + a.elapsed_time(b), m)
-        return {k: (c, t / c, m) for k, (c, t, m) in out.items()}
+            key = (name, tuple(sorted(meta.items())))
+            c, t, m = groups.get(key, (0, 0.0, meta))
+            groups[key] = (c + 1, t + a.elapsed_time(b), m)
+        by_name = {}
+        for (name, _), v in groups.items():
+            by_name.setdefault(name, []).append(v)
+        out = {}
+        for name, vs in by_name.items():
+            if len(vs) == 1:
+                c, t, m = vs[0]
+                out[name] = (c, t / c, m)
+                continue
+            common = set.intersection(*[set(m.items()) for _, _, m in vs])
+            for c, t, m in vs:
+                diff = ",".join("%s=%s" % kv for kv in sorted(set(m.items()) - common))
+                out["%s|%s" % (name, diff)] = (c, t / c, m)
+        return out
 
 
 TIMER = None
+
+
+def _new_event():
+    """HIP event on the launch stream (a seam the CPU tests replace with a fake clock)."""
+    return torch.cuda.Event(enable_timing=True)
 
 
 class _timed:
@@ -72,12 +121,18 @@ class _timed:
     def __enter__(self):
         self.on = TIMER is not None and (TIMER.prefixes is None or self.name.startswith(TIMER.prefixes))
         if self.on:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.b = torch.cuda.Event(enable_timing=True)
+            self.a = _new_event()
+            self.b = _new_event()
             self.a.record()
 
+        return self
+
+    def cancel(self):
+        """Nothing was launched inside the block (the entry point declined the shape): record no interval."""
+        self.on = False
+
     def __exit__(self, *exc):
-        if self.on and TIMER is not None:
+        if self.on and TIMER is not None and exc[0] is None:
             self.b.record()
             TIMER.records.append((self.name, self.meta, self.a, self.b))
         return False
@@ -177,13 +232,15 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
             if pending is not None:
                 # the previous layer's BatchNorm + ReLU + readout ride on this aggregation's tile load
                 z, scale, shift, hout, gslice = pending
-                with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1):
+                with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1) as tm:
                     rc = lib.gnm_agg_fwd_bnrelu(
                         a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
                         batch.col_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max,
                         z.data_ptr(), z.stride(0), scale.data_ptr(), shift.data_ptr(), hout.data_ptr(),
                         hout.stride(0), gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), pooled.data_ptr(),
                         pooled.stride(0), F_l, eps_ptr, int(spec.n_avg), int(not spec.learn_eps), _stream())
+                    if rc != 0:
+                        tm.cancel()       # declined (or failed): no launch happened, the fallback below times itself
                 if rc == -2:
                     readout(*pending)
                 else:
@@ -245,10 +302,12 @@ class GinInfoMaxFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, P0, X, *tensors):
-        if not X.is_cuda:
-            raise GnmError("the GIN hot path runs on the GPU only (libgnm_hip.so); got a %s tensor" % X.device)
+        dev = launch_device(X, P0, *tensors)
+        adev = batch.arena.device
+        if adev.type != "cuda" or (adev.index is not None and adev.index != dev.index):
+            raise GnmError("the batch's graph arena lives on %s, the model on %s" % (adev, dev))
         ctx.set_materialize_grads(False)
-        with _stream_scope():
+        with _stream_scope(dev):
             return GinInfoMaxFn._forward(ctx, spec, batch, perm, names, buffers, training, dropout_p, want_disc, P0,
                                          X, tensors)
 
@@ -321,7 +380,7 @@ class GinInfoMaxFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dC, dD, _dgf):
-        with _stream_scope():
+        with _stream_scope(ctx.g_f.device):
             return GinInfoMaxFn._backward(ctx, dC, dD)
 
     @staticmethod
@@ -490,7 +549,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                 lo_part = None
                 if lo is not None and need_dA:
                     lo_part = torch.empty((lib.gnm_linear_bwd_grid(N), 2, K), dtype=torch.float64, device=dev)
-                with _timed("linbwd_K%d_H%d" % (K, Hk), N=N, K=K, H=Hk):
+                with _timed("linbwd_K%d_H%d" % (K, Hk), N=N, K=K, H=Hk) as tm:
                     rc = lib.gnm_linear_bwd_fused(
                         G.data_ptr(), G.stride(0), sv.z.data_ptr(), sv.z.stride(0), sv.mean.data_ptr(),
                         sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), sv.x_in.data_ptr(),
@@ -502,6 +561,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                         lo.shift.data_ptr() if lo_part is not None else None,
                         lo.mean.data_ptr() if lo_part is not None else None,
                         lo.rstd.data_ptr() if lo_part is not None else None, ptr(lo_part), st)
+                    if rc != 0:
+                        tm.cancel()
                 if rc == 0 and lo_part is not None:
                     pre_stats = (dA, lo_part, lo_part.shape[0])
                 if rc == -2:        # GNM_ERR_UNSUPPORTED: generic three-kernel path
@@ -543,7 +604,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                     dplo = dph[l - 1]
                     spart = torch.empty((B, 2, F_l), dtype=torch.float64, device=dev)
                     a = batch.arena
-                    with _timed("agg_bwd_F%d" % F_l, F=F_l, B=B, N=N):
+                    with _timed("agg_bwd_F%d" % F_l, F=F_l, B=B, N=N, fused_stats=1) as tm:
                         rc = lib.gnm_agg_bwd_stats(
                             a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
                             batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
@@ -556,6 +617,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                             ptr(dsc1) if use_disc else None, ptr(Ulo), U.stride(0) if use_disc else 0,
                             ptr(inv_perm) if use_disc else None, ptr(s2sum) if use_disc else None, spart.data_ptr(),
                             st)
+                        if rc != 0:
+                            tm.cancel()
                     if rc == 0:
                         fused = True
                         pre_outer = (dh, spart, B)

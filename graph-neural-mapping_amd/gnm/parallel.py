@@ -32,14 +32,21 @@ class FlatParams:
             off += n
         self.total = total
 
-    def zero_grad(self):
-        self.flat_grad.zero_()
+    def attach_grads(self):
+        """Make every parameter's .grad the view of the flat gradient buffer again.  optimizer.zero_grad() and
+        module.zero_grad() default to set_to_none=True (and GIN_InfoMaxReg.compute_saliency calls the latter), and
+        autograd may replace .grad: an optimizer that finds .grad None silently skips the parameter."""
         off = 0
-        for p in self.params:      # autograd may have replaced .grad; re-attach the views
+        base = self.flat_grad.data_ptr()
+        for p in self.params:
             n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                 p.grad = self.flat_grad[off:off + n].view_as(p.data)
             off += n
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        self.attach_grads()
 
 
 class _BnSync:
@@ -72,6 +79,7 @@ class DataParallelGIN:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.fp = FlatParams(model)
+        self._stage = None          # pinned host staging buffer of the gloo-with-device-tensors path
         # GIN_InfoMaxReg: let the backward kernels write gradients straight into the flat buffer
         # (overwrite semantics: every step produces every gradient, so no zeroing and no
         # AccumulateGrad adds are needed; see GinSpec.grad_sink)
@@ -106,18 +114,37 @@ class DataParallelGIN:
 
     def zero_grad(self):
         if self.direct:
-            return          # every gradient is overwritten by the next backward
+            # every gradient is overwritten by the next backward, so nothing is zeroed; but the .grad views must
+            # be in place: a stock optimizer's zero_grad() (set_to_none=True) detaches them and would then skip
+            # every parameter, because the sink backward hands autograd None
+            self.fp.attach_grads()
+            return
         self.fp.zero_grad()
 
     def allreduce_gradients(self, async_op=False):
         """Sum over ranks then scale by 1/W (the mean-loss convention of main.py:34-37
         applied to the union batch)."""
+        self.fp.attach_grads()      # callers that only ran optimizer.zero_grad(): see zero_grad()
         if self.world == 1:
             return None
-        work = dist.all_reduce(self.fp.flat_grad, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        g = self.fp.flat_grad
+        if g.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no device path worth the name: handing it a CUDA tensor makes it stage through pageable
+            # memory on internal streams (measured 8 ms for 569 KB, and 300 ms when a hipGraph replay was still in
+            # flight on a GPU shared by two ranks).  Stage explicitly through ONE pinned buffer instead.  This is
+            # the CPU-test / shared-GPU test-hook path; RCCL ("nccl") reduces the device buffer in place.
+            if self._stage is None:
+                self._stage = torch.empty(g.numel(), dtype=g.dtype).pin_memory()
+            self._stage.copy_(g, non_blocking=True)
+            torch.cuda.current_stream(g.device).synchronize()
+            dist.all_reduce(self._stage, op=dist.ReduceOp.SUM, group=self.group)
+            self._stage.div_(self.world)
+            g.copy_(self._stage, non_blocking=True)
+            return None
+        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
             return work
-        self.fp.flat_grad.div_(self.world)
+        g.div_(self.world)
         return None
 
 

@@ -54,6 +54,15 @@ def knn_graph(g, n=1000, k=20, dim=8, f0=7):
     return SynthGraph(n, np.stack([iu, ju], 1), feats, int(rng.integers(0, 2)))
 
 
-def make_pool(kind, count, first=0, **kw):
+def make_pool(kind, count, first=0, threads=None, **kw):
+    """count graphs with ids first .. first+count-1 (each graph is a pure function of its id).  Generation is
+    numpy-bound (corrcoef, percentile sort) and releases the GIL, so large pools are built on a few threads."""
     fn = dense_fc_graph if kind == "dense_fc" else knn_graph
-    return [fn(first + i, **kw) for i in range(count)]
+    if threads is None:
+        import os
+        threads = min(16, os.cpu_count() or 1)
+    if count < 64 or threads <= 1:
+        return [fn(first + i, **kw) for i in range(count)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(lambda i: fn(first + i, **kw), range(count)))

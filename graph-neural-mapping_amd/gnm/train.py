@@ -44,7 +44,7 @@ class _InfomaxLossFn(torch.autograd.Function):
         lab = labels.to(torch.int64).contiguous()
         if lab.numel() != B:
             raise ValueError("labels has %d entries, c_logit %d rows" % (lab.numel(), B))
-        with _stream_scope():
+        with _stream_scope(dev):
             check(lib.gnm_loss_ce_bce(c.data_ptr(), c.stride(0), lab.data_ptr(), B, C_, d.data_ptr(),
                                       tgt.data_ptr() if tgt is not None else None, M, int(n_pos), float(beta),
                                       loss3.data_ptr(), None, 0, None, ws.data_ptr(), _stream()), "gnm_loss_ce_bce")
@@ -60,7 +60,7 @@ class _InfomaxLossFn(torch.autograd.Function):
         M = d.numel()
         g = g.to(torch.float32).contiguous()
         dC, dD = torch.empty_like(c), torch.empty_like(d)
-        with _stream_scope():      # both gradients, already multiplied by the upstream gradient, in one launch
+        with _stream_scope(c.device):      # both gradients, already multiplied by the upstream gradient, in one launch
             check(lib.gnm_loss_ce_bce_grad(c.data_ptr(), c.stride(0), lab.data_ptr(), B, C_, d.data_ptr(),
                                            tgt.data_ptr() if tgt is not None else None, M, n_pos, beta, g.data_ptr(),
                                            dC.data_ptr(), dC.stride(0), dD.data_ptr(), _stream()),
@@ -112,7 +112,7 @@ class FusedAdam:
         self.fp.zero_grad()
 
     def step(self):
-        with _stream_scope():
+        with _stream_scope(self.fp.flat.device):
             check(lib.gnm_adam_step(self.fp.flat.data_ptr(), self.fp.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
                                     self.exp_avg_sq.data_ptr(), self.fp.total, self.hyper.data_ptr(),
                                     self.step_count.data_ptr(), _stream()), "gnm_adam_step")

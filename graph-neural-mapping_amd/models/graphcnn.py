@@ -40,6 +40,8 @@ class GIN_InfoMaxReg(nn.Module):
     def __init__(self, num_layers, num_mlp_layers, input_dim, hidden_dim, output_dim, final_dropout, learn_eps,
                  graph_pooling_type, neighbor_pooling_type, device):
         super().__init__()
+        if neighbor_pooling_type != "max":
+            self._check_kernel_limits(num_layers, input_dim, hidden_dim)
         # creation order follows graphcnn.py:29-52 so torch.manual_seed(s) yields the same weights
         self.disc = Discriminator(hidden_dim * num_layers)
         self.sigm = nn.Sigmoid()
@@ -62,6 +64,22 @@ class GIN_InfoMaxReg(nn.Module):
         self._spec = GinSpec(num_layers, num_mlp_layers, learn_eps, graph_pooling_type, neighbor_pooling_type)
         self._arena = None
         self._plist = None
+
+    @staticmethod
+    def _check_kernel_limits(num_layers, input_dim, hidden_dim):
+        """Shapes the HIP kernels are built for (narrower than the reference, which takes anything torch does):
+        said here, at construction, rather than as GNM_ERR_BAD_ARG from the first forward."""
+        from gnm._cabi import lib
+        if hidden_dim < 4 or hidden_dim > 128 or hidden_dim % 4:
+            raise ValueError("hidden_dim=%d: the MI355X kernels take a multiple of 4 in [4, 128] (BatchNorm / Linear "
+                             "column tiles; csrc/norm.hip, csrc/linear.hip)" % hidden_dim)
+        if num_layers < 1 or num_layers > 16:
+            raise ValueError("num_layers=%d: 1..16 GIN layers are supported (csrc/disc.hip GNM_MAX_LAYERS)" % num_layers)
+        kmax = int(lib.gnm_linear_max_k(hidden_dim))
+        if input_dim < 1 or input_dim > kmax:
+            raise ValueError("input_dim=%d with hidden_dim=%d: the first Linear keeps its [input_dim x hidden_dim] "
+                             "weight in LDS, which bounds input_dim to %d (csrc/linear.hip)"
+                             % (input_dim, hidden_dim, kmax))
 
     # ------------------------------------------------------------------ plumbing
     def arena(self):

@@ -10,8 +10,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name ends in _host;
  *   - matrices are fp32 row-major with an explicit leading dimension (in floats);
- *   - `stream` is a hipStream_t passed as void*; nothing synchronises, allocates or
- *     keeps global state (hipGraph-capturable);
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises or allocates
+ *     (hipGraph-capturable).  The only process state is launch configuration: a
+ *     per-(kernel, device) flag that hipFuncSetAttribute(MaxDynamicSharedMemorySize) has been
+ *     applied on that device, and tuning knobs read from the environment once per process;
  *   - return value: 0 on success, >0 a hipError_t, <0 GNM_ERR_* below.
  *
  * Batch description (replaces the int64 block-diagonal COO built per forward at
@@ -39,6 +41,10 @@ extern "C" {
 #define GNM_ERR_UNSUPPORTED (-2)
 
 const char* gnm_version(void);
+/* Test hook: one instance of the per-device "configure once" guard that every launcher keeps for
+ * hipFuncSetAttribute(MaxDynamicSharedMemorySize) -- 1 the first time `device` is seen, 0 afterwards;
+ * reset != 0 clears it.  Touches no device. */
+int gnm_debug_device_once(int device, int reset);
 
 /* ---- host helpers (no GPU needed) ------------------------------------------------ */
 
@@ -115,6 +121,9 @@ int gnm_sum_partials_multi(const double* partial, long long stride, const int* c
  * stats_partial (optional): [gnm_linear_grid(N)][2][H] doubles, per-column sum and sum
  * of squares of Z for the BatchNorm that follows.  H <= 128 per call. */
 int gnm_linear_grid(int N);
+/* Largest input width K gnm_linear_fwd accepts for output width H (0: H unsupported; H <= 128).  The weight
+ * stays LDS-resident, so K is bounded: 448 at H = 64, 192 at H = 128. */
+int gnm_linear_max_k(int H);
 int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, int w_kmajor, const float* bias, float* Z,
                    int ldz, int N, int K, int H, const float* pro_scale, const float* pro_shift, int pro_relu,
                    double* stats_partial, void* stream);

@@ -172,10 +172,12 @@ class OracleGIN:
         return y, cache
 
     # -- forward ---------------------------------------------------------------
-    def forward(self, batch, perm, training=False, dropout_masks=None, update_running=True):
+    def forward(self, batch, perm, training=False, dropout_masks=None, update_running=True, want_disc=True):
         """graphcnn.py:194-251.  `perm` is the np.random.permutation(B) the
         reference draws at :199.  dropout_masks: optional list of [B,C] keep/(1-p)
-        multipliers (F.dropout at :230); None means p == 0 or eval mode."""
+        multipliers (F.dropout at :230); None means p == 0 or eval mode.
+        want_disc=False stops after the classifier (:231) and returns d_logit = None: the
+        "encoder + classifier only" variant of the timed CPU baseline."""
         dt = self.dtype
         L, m = self.L, self.m
         B = len(batch)
@@ -233,6 +235,10 @@ class OracleGIN:
                 lg = lg * dropout_masks[l]
             c_logit = c_logit + lg
             pooled_h.append(ph)
+        if not want_disc:
+            cache.update(hidden=hidden, pooled_h=pooled_h, n_f=None, g_f=np.concatenate(pooled_h, 1),
+                         dropout_masks=dropout_masks if training else None)
+            return c_logit, None, cache
         n_f = np.concatenate(hidden, 1)                                       # :233
         g_f = np.concatenate(pooled_h, 1)                                     # :234
         c = sigmoid(g_f)                                                      # :239
@@ -262,19 +268,22 @@ class OracleGIN:
         A, P, deg = cache["A"], cache["P"], cache["deg"]
         grads = {}
         dC = np.asarray(d_c_logit, dtype=dt)
-        dD = np.asarray(d_d_logit, dtype=dt)
-        dsc1, dsc2 = dD[:N], dD[N:]
-        Wd = self.p["disc.f_k.weight"][0]
-        n_f, shuf, c_x, c = cache["n_f"], cache["shuf"], cache["c_x"], cache["c"]
-        # nn.Bilinear backward: dW = x1^T (dy * x2); dx1 = dy * (x2 W^T); dx2 = dy * (x1 W)
-        grads["disc.f_k.weight"] = (n_f.T @ (dsc1 * c_x) + shuf.T @ (dsc2 * c_x))[None]
-        grads["disc.f_k.bias"] = np.array([dsc1.sum() + dsc2.sum()], dtype=dt)
-        cW = c_x @ Wd.T
-        dn_f = dsc1 * cW
-        np.add.at(dn_f, cache["idx"], dsc2 * cW)                              # gather backward (graphcnn.py:242)
-        dc_x = dsc1 * cache["t1"] + dsc2 * cache["t2"]
-        dc = dc_x.reshape(B, N // B, -1).sum(1)
-        dg_f = dc * c * (1 - c)                                               # sigmoid backward
+        with_disc = cache["n_f"] is not None and d_d_logit is not None
+        dn_f = dg_f = None
+        if with_disc:
+            dD = np.asarray(d_d_logit, dtype=dt)
+            dsc1, dsc2 = dD[:N], dD[N:]
+            Wd = self.p["disc.f_k.weight"][0]
+            n_f, shuf, c_x, c = cache["n_f"], cache["shuf"], cache["c_x"], cache["c"]
+            # nn.Bilinear backward: dW = x1^T (dy * x2); dx1 = dy * (x2 W^T); dx2 = dy * (x1 W)
+            grads["disc.f_k.weight"] = (n_f.T @ (dsc1 * c_x) + shuf.T @ (dsc2 * c_x))[None]
+            grads["disc.f_k.bias"] = np.array([dsc1.sum() + dsc2.sum()], dtype=dt)
+            cW = c_x @ Wd.T
+            dn_f = dsc1 * cW
+            np.add.at(dn_f, cache["idx"], dsc2 * cW)                          # gather backward (graphcnn.py:242)
+            dc_x = dsc1 * cache["t1"] + dsc2 * cache["t2"]
+            dc = dc_x.reshape(B, N // B, -1).sum(1)
+            dg_f = dc * c * (1 - c)                                           # sigmoid backward
         dh_next = None
         for l in reversed(range(L)):
             lc = cache["layers"][l]
@@ -282,8 +291,12 @@ class OracleGIN:
             dlg = dC if cache["dropout_masks"] is None else dC * cache["dropout_masks"][l]
             grads[f"linears_prediction.{l}.weight"] = dlg.T @ cache["pooled_h"][l]
             grads[f"linears_prediction.{l}.bias"] = dlg.sum(0)
-            dph = dlg @ Wp + dg_f[:, l * H:(l + 1) * H]
-            dh = P.T @ dph + dn_f[:, l * H:(l + 1) * H]
+            dph = dlg @ Wp
+            if with_disc:
+                dph = dph + dg_f[:, l * H:(l + 1) * H]
+            dh = P.T @ dph
+            if with_disc:
+                dh = dh + dn_f[:, l * H:(l + 1) * H]
             if dh_next is not None:
                 dh = dh + dh_next
             bnc, mask = lc["bn_out"]
@@ -343,13 +356,19 @@ class OracleGIN:
         dD = (sigmoid(x) - y) / x.size
         return c_loss + beta * d_loss, c_loss, d_loss, dC, beta * dD
 
-    def train_step_grads(self, batch, perm, beta=0.05, dropout_masks=None, update_running=True):
+    def train_step_grads(self, batch, perm, beta=0.05, dropout_masks=None, update_running=True, want_disc=True):
         """One main.py:29-40 step without the optimizer: forward (train mode),
-        loss, backward.  d_labels sized by node count (SURVEY 8(b) caller quirk)."""
+        loss, backward.  d_labels sized by node count (SURVEY 8(b) caller quirk).
+        want_disc=False: the loss is CrossEntropy(c_logit) alone and the Infomax tail is not computed."""
         c_logit, d_logit, cache = self.forward(batch, perm, training=True, dropout_masks=dropout_masks,
-                                               update_running=update_running)
+                                               update_running=update_running, want_disc=want_disc)
         N = cache["N"]
         c_labels = np.asarray([g.label for g in batch], dtype=np.int64)
+        if not want_disc:
+            loss, c_loss, _, dC, _ = self.losses(c_logit, np.zeros((1, 1), self.dtype), c_labels,
+                                                 np.zeros((1, 1), self.dtype), 0.0)
+            grads = self.backward(cache, dC, None)
+            return dict(loss=c_loss, c_loss=c_loss, d_loss=0.0, c_logit=c_logit, d_logit=None, grads=grads, cache=cache)
         d_labels = np.concatenate([np.ones((N, 1)), np.zeros((N, 1))], 0).astype(self.dtype)
         loss, c_loss, d_loss, dC, dD = self.losses(c_logit, d_logit, c_labels, d_labels, beta)
         grads = self.backward(cache, dC, dD)

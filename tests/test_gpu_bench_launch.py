@@ -1,0 +1,27 @@
+"""`python bench.py --gpus 2` end to end on the one-GPU box: no launcher, the two ranks share cuda:0 over gloo
+(GNM_BENCH_SHARE_GPU=1, the bench's test hook) -- everything of the N > 1 path except RCCL itself: self-launch,
+per-rank pools, hipGraph replay or eager, the flat-gradient all-reduce, max-over-ranks timing, one JSON line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_without_a_launcher():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["GNM_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "32", "--pool", "64",
+                        "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 64 and out["config"]["graphs_per_gpu"] == 32
+    assert out["value"] > 0 and out["ms_per_step"] < 200, out["ms_per_step"]     # round 1: 279-404 ms through gloo

@@ -1,6 +1,15 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the aggregation kernel alone (forward, F = 64) through the C-ABI:
-mean launch time from HIP events, canonical GB/s and graph-layers/s."""
+"""Micro-benchmark of the aggregation kernel alone (F = 64 by default) through the C-ABI: median launch time from
+HIP events, canonical GB/s and graph-layers/s, for the launch forms a training step uses:
+
+  plain     gnm_agg forward
+  fused     gnm_agg_fwd_bnrelu (previous layer's BatchNorm+ReLU+readout on the tile load: what a step's layers 1.. run)
+  bwd       gnm_agg backward with the d-eps dot product on the way in
+  bwdstats  gnm_agg_bwd_stats (backward + the layer below's BatchNorm-backward pass 1: what a step's backward runs)
+  phasea    y = null: tile load + barrier only
+
+  python tools/bench_agg.py --modes plain,fused,bwdstats [--cold]
+--cold streams 1 GiB between launches so inputs come from HBM, not from the Infinity Cache."""
 import argparse
 import os
 import sys
@@ -17,79 +26,99 @@ from gnm.arena import GraphArena
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--pool", type=int, default=256)
+    ap.add_argument("--pool", type=int, default=1024)
     ap.add_argument("--F", type=int, default=64)
     ap.add_argument("--iters", type=int, default=30)
-    ap.add_argument("--backward", action="store_true")
-    ap.add_argument("--fused", action="store_true",
-                    help="gnm_agg_fwd_bnrelu: previous layer's BatchNorm+ReLU+readout on the tile load (what a step runs)")
-    ap.add_argument("--phase-a-only", action="store_true", help="y = null: tile load + barrier only")
+    ap.add_argument("--modes", default="plain,fused,bwdstats")
+    ap.add_argument("--cold", action="store_true")
+    ap.add_argument("--tag", default=os.environ.get("GNM_HIP_LIB", "product"))
+    ap.add_argument("--check", action="store_true", help="spot-check the result against a dense fp64 product")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     pool = synth.make_pool("dense_fc", args.pool)
     ar = GraphArena(dev)
-    gids = np.array([ar.add(g) for g in pool], dtype=np.int64)
+    gids = np.array(ar.add_many(pool), dtype=np.int64)
     rng = np.random.default_rng(0)
-    batch = ar.batch_from_gids(gids[rng.integers(0, args.pool, args.batch)])
-    N, F = batch.N, args.F
+    sel = rng.permutation(args.pool)[:args.batch] if args.pool >= args.batch else rng.integers(0, args.pool, args.batch)
+    batch = ar.batch_from_gids(gids[sel])
+    N, F, B = batch.N, args.F, batch.B
     E = int(pool[0].edge_mat.shape[1])
     x = torch.randn(N, F, device=dev)
     h = torch.randn(N, F, device=dev)
     y = torch.empty(N, F, device=dev)
     eps = torch.zeros(1, device=dev)
     spec = core.GinSpec(5, 2, True, "sum", "sum")
-    part = torch.empty(core.lib.gnm_agg_num_partials(F, batch.n_max, batch.B), dtype=torch.float64, device=dev)
-
+    part = torch.empty(core.lib.gnm_agg_num_partials(F, batch.n_max, B), dtype=torch.float64, device=dev)
     sc, sh = torch.rand(F, device=dev) + 0.5, torch.randn(F, device=dev) * 0.3
-    gf = torch.empty(batch.B, F, device=dev)
+    mu, rs = torch.randn(F, device=dev) * 0.1, torch.rand(F, device=dev) + 0.5
+    gf = torch.empty(B, F, device=dev)
+    dpool = torch.randn(B, F, device=dev)
+    U = torch.randn(B, F, device=dev)
+    dsc1 = torch.randn(N, device=dev)
+    inv_perm = torch.randperm(B, device=dev).to(torch.int32)
+    s2sum = torch.randn(B, device=dev)
+    spart = torch.empty(B, 2, F, dtype=torch.float64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+    a = ar
+    flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if args.cold else None
 
-    def run():
-        if args.fused:
+    def run(mode):
+        if mode == "fused":
             core.check(core.lib.gnm_agg_fwd_bnrelu(
-                ar.rowptr.buf.data_ptr(), ar.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
-                batch.node_off.data_ptr(), batch.B, batch.n_max, batch.nnz_max, x.data_ptr(), F, sc.data_ptr(),
+                a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
+                batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, x.data_ptr(), F, sc.data_ptr(),
                 sh.data_ptr(), h.data_ptr(), F, gf.data_ptr(), F, 0, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, st),
                 "gnm_agg_fwd_bnrelu")
-        elif args.backward:
+        elif mode == "bwd":
             core._agg(batch, x, y, F, eps.data_ptr(), spec, True, hfwd=h, deps_partial=part)
-        elif args.phase_a_only:
+        elif mode == "bwdstats":
+            core.check(core.lib.gnm_agg_bwd_stats(
+                a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(), batch.t_col_off.data_ptr(),
+                a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max,
+                batch.nnz_max, x.data_ptr(), F, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, None, 0, part.data_ptr(),
+                h.data_ptr(), F, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), dpool.data_ptr(), F, 0,
+                dsc1.data_ptr(), U.data_ptr(), F, inv_perm.data_ptr(), s2sum.data_ptr(), spart.data_ptr(), st),
+                "gnm_agg_bwd_stats")
+        elif mode == "phasea":
             core._agg(batch, x, None, F, eps.data_ptr(), spec, False)
         else:
             core._agg(batch, x, y, F, eps.data_ptr(), spec, False)
 
-    for _ in range(5):
-        run()
-    torch.cuda.synchronize()
-    evs = []
-    for _ in range(args.iters):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); run(); b.record()
-        evs.append((a, b))
-    torch.cuda.synchronize()
-    ms = np.array([a.elapsed_time(b) for a, b in evs])
     byt = (4 * 400 * F * 2 + 4 * E + 4 * 401) * args.batch
-    med = float(np.median(ms))
-    print("agg %s F=%d B=%d: median %.1f us (min %.1f)  %.0f GB/s canonical (%.1f%% of 8 TB/s)  %.2f M graph-layers/s"
-          % ("bwd" if args.backward else "fwd", F, args.batch, med * 1e3, ms.min() * 1e3, byt / med / 1e6,
-             100 * byt / med / 1e6 / 8000, args.batch / med / 1e3))
-    # correctness spot check vs a dense torch reference on one graph
-    g0 = pool[int(rng.integers(0, 1))]
-    b1 = ar.batch_from_gids(gids[:2])
-    x1 = torch.randn(b1.N, F, device=dev)
-    y1 = torch.empty_like(x1)
-    core._agg(b1, x1, y1, F, eps.data_ptr(), spec, False)
-    ref = []
-    for k in range(2):
-        em = pool[k].edge_mat.to(dev)
-        A = torch.zeros(400, 400, device=dev, dtype=torch.float64)
-        A.index_put_((em[0], em[1]), torch.ones(em.shape[1], device=dev, dtype=torch.float64), accumulate=True)
-        xs = x1[400 * k:400 * (k + 1)].double()
-        ref.append(A @ xs + xs)
-    ref = torch.cat(ref)
-    err = (y1.double() - ref).abs().max().item() / ref.abs().max().item()
-    print("spot check vs dense fp64: rel err %.2e" % err)
-    assert err < 1e-5
+    for mode in args.modes.split(","):
+        for _ in range(5):
+            run(mode)
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(args.iters):
+            if flush is not None:
+                flush.add_(1.0)
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ea.record(); run(mode); eb.record()
+            evs.append((ea, eb))
+        torch.cuda.synchronize()
+        ms = np.array([ea.elapsed_time(eb) for ea, eb in evs])
+        med = float(np.median(ms))
+        print("AGG %-28s %-8s F=%d B=%d%s: median %.1f us (min %.1f)  %.0f GB/s canonical = %.3f of 8 TB/s  "
+              "%.2f M graph-layers/s" % (os.path.basename(str(args.tag)), mode, F, args.batch,
+                                         " cold" if args.cold else "", med * 1e3, ms.min() * 1e3, byt / med / 1e6,
+                                         byt / med / 1e6 / 8000, args.batch / med / 1e3), flush=True)
+    if args.check:
+        b1 = ar.batch_from_gids(gids[:2])
+        x1 = torch.randn(b1.N, F, device=dev)
+        y1 = torch.empty_like(x1)
+        core._agg(b1, x1, y1, F, eps.data_ptr(), spec, False)
+        ref = []
+        for k in range(2):
+            em = pool[k].edge_mat.to(dev)
+            A = torch.zeros(400, 400, device=dev, dtype=torch.float64)
+            A.index_put_((em[0], em[1]), torch.ones(em.shape[1], device=dev, dtype=torch.float64), accumulate=True)
+            xs = x1[400 * k:400 * (k + 1)].double()
+            ref.append(A @ xs + xs)
+        ref = torch.cat(ref)
+        err = (y1.double() - ref).abs().max().item() / ref.abs().max().item()
+        print("spot check vs dense fp64: rel err %.2e" % err)
+        assert err < 1e-5
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_agg_$TAG
 mkdir -p $OUT
 run() { name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/tools/bench_agg.py --iters 10 $EXTRA > $OUT/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/tools/bench_agg.py --iters 10 --modes ${EXTRA:-plain} > $OUT/$name.log 2>&1
   echo "$name exit $?"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
