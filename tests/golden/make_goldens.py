@@ -101,6 +101,8 @@ def build_model(seed, L, m, f0, H, C, dropout, learn_eps, gpool, npool):
 
 def run_case(tag, model_seed, graph_seed, B, n, t, L, m, f0, H, C, learn_eps, gpool, npool,
              state_file, row_stride=1, full_disc_grad=True):
+    if ONLY is not None and not tag.startswith(ONLY):
+        return
     graphs, raw = make_batch(graph_seed, B, n, t, f0)
     out = {}
     out["cfg"] = np.array([L, m, f0, H, C, int(learn_eps), B, n], dtype=np.int64)
@@ -220,7 +222,13 @@ def run_case(tag, model_seed, graph_seed, B, n, t, L, m, f0, H, C, learn_eps, gp
     print(f"{tag}: {os.path.getsize(path)/1024:.0f} KB")
 
 
+ONLY = None     # python tests/golden/make_goldens.py --only true_   regenerates the cases with that prefix
+
+
 def main():
+    global ONLY
+    if "--only" in sys.argv:
+        ONLY = sys.argv[sys.argv.index("--only") + 1]
     # seed 0: the reference's default dims (main.py:113-115) at F_0 = 7 (BASELINE configs)
     s0 = os.path.join(HERE, "state_seed0.npz")
     combos0 = [(True, "sum", "sum"), (True, "average", "average"),
@@ -246,6 +254,16 @@ def main():
     # true shape: n=400, 47,600 directed edges/graph; per-node arrays row-subsampled
     run_case("true_s0_eps1_gsum_nsum", 0, 1000, B=2, n=400, t=256, L=5, m=2, f0=7, H=64, C=2,
              learn_eps=True, gpool="sum", npool="sum", state_file=s0, row_stride=16, full_disc_grad=False)
+    # the other aggregation / readout forms at true shape (round 2; BASELINE configs[4] mixes sum and average
+    # pooling at n = 400): the self-loop form next_layer (graphcnn.py:170-191) with average neighbour pooling
+    # (:181-182, divides by deg + 1) and sum readout; next_layer_eps with average neighbour pooling (:155-158)
+    # and average readout (:122-123); the self-loop form with sum neighbours and average readout
+    run_case("true_s0_eps0_gsum_naverage", 0, 1000, B=2, n=400, t=256, L=5, m=2, f0=7, H=64, C=2,
+             learn_eps=False, gpool="sum", npool="average", state_file=s0, row_stride=16, full_disc_grad=False)
+    run_case("true_s0_eps1_gaverage_naverage", 0, 1000, B=2, n=400, t=256, L=5, m=2, f0=7, H=64, C=2,
+             learn_eps=True, gpool="average", npool="average", state_file=s0, row_stride=16, full_disc_grad=False)
+    run_case("true_s0_eps0_gaverage_nsum", 0, 1000, B=2, n=400, t=256, L=5, m=2, f0=7, H=64, C=2,
+             learn_eps=False, gpool="average", npool="sum", state_file=s0, row_stride=16, full_disc_grad=False)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,17 @@ TRUE_SHAPE_FACTOR = 4.0
 # the reference happened not to flip).  True-shape gradients are therefore
 # compared with the fp64 oracle at 5e-3; the tiny cases keep 5e-5.
 TRUE_SHAPE_GRAD_RTOL = 5e-3
+# A mask bit can also flip between fp32 and fp64 arithmetic as such: in true_s0_eps1_gaverage_naverage the
+# reference and the numpy-fp32 oracle agree with each other to 1e-4 on every gradient but BOTH sit 1.5e-2 from the
+# fp64 oracle (a pre-activation within fp32 rounding of zero: every fp32 implementation takes one side, exact
+# arithmetic the other).  A correct fp32 gradient therefore matches the reference's golden OR the fp64 oracle
+# (whichever decided its borderline masks the same way) -- assert_grad_true_shape below -- and the two anchors
+# may themselves be this far apart:
+TRUE_SHAPE_GRAD_ANCHOR_GAP = 5e-2
+# The numpy-fp32 oracle is a noisier fp32 implementation than either torch or the HIP path (naive fp32 column
+# sums in BatchNorm, sequential fp32 spmm): its own deep-layer activations get this factor instead of
+# TRUE_SHAPE_FACTOR.  It is not the product; the pin is the fp64 oracle against the goldens.
+ORACLE32_FACTOR = 10.0
 
 
 def golden_cases(prefix=""):
@@ -85,6 +96,20 @@ def assert_close(a, ref, rtol=RTOL, what="", floor=0.0):
     return e
 
 
+def assert_grad_true_shape(a, golden, truth64, what="", floor=0.0, rtol=TRUE_SHAPE_GRAD_RTOL):
+    """True-shape gradient check (see TRUE_SHAPE_GRAD_RTOL / TRUE_SHAPE_GRAD_ANCHOR_GAP): `a` must be within rtol of
+    the reference's golden or of the fp64 oracle; golden=None (tensor not stored) leaves the fp64 oracle.
+    Returns (err vs golden or None, err vs fp64)."""
+    e_t = rel_err(a, truth64, floor)
+    e_g = rel_err(a, golden, floor) if golden is not None else None
+    if golden is not None:
+        gap = rel_err(golden, truth64, floor)
+        assert gap <= TRUE_SHAPE_GRAD_ANCHOR_GAP, f"{what}: golden is {gap:.2e} from the fp64 oracle"
+    best = e_t if e_g is None else min(e_t, e_g)
+    assert best <= rtol, f"{what}: err vs golden {e_g}, vs fp64 oracle {e_t:.3e} > {rtol:.1e}"
+    return e_g, e_t
+
+
 class Calibrated:
     """Calibrated comparison for the true-shape case (see TRUE_SHAPE_FACTOR).
     Keeps the running maximum of the reference's own error vs the fp64 oracle
@@ -94,6 +119,7 @@ class Calibrated:
         self.base = base_rtol
         self.factor = factor
         self.noise = 0.0
+        self.log = []          # (what, error of the checked value vs fp64, the reference's own error, bound applied)
 
     def check(self, a, golden, truth64, what="", floor=0.0):
         ref_noise = rel_err(golden, truth64, floor)
@@ -102,4 +128,5 @@ class Calibrated:
         bound = max(self.base, self.factor * self.noise)
         e = rel_err(a, truth64, floor)
         assert e <= bound, f"{what}: err vs fp64 oracle {e:.3e} > {bound:.2e} (reference noise {self.noise:.2e})"
+        self.log.append((what, e, ref_noise, bound))
         return e

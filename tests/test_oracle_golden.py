@@ -7,7 +7,8 @@ float32 outputs (it is the build's only fp64 cross-check)."""
 import numpy as np
 import pytest
 
-from helpers import (RTOL, TRUE_SHAPE_GRAD_RTOL, Calibrated, assert_close, edge_mat_of, golden_cases, grad_floor,
+from helpers import (ORACLE32_FACTOR, RTOL, TRUE_SHAPE_GRAD_RTOL, Calibrated, assert_close, assert_grad_true_shape,
+                     edge_mat_of, golden_cases, grad_floor,
                      load_case)
 from oracle import gin_oracle as O
 
@@ -75,7 +76,7 @@ def test_train_step(case, dtype):
         truth_model = make_model(cfg, state, np.float64)
         truth_out = truth_model.train_step_grads(batch, d["perm"], beta=0.05)
         truth = truth_out["cache"]
-        cal = Calibrated()
+        cal = Calibrated(factor=ORACLE32_FACTOR if dtype == np.float32 else 1.0)
         for l in range(cfg["L"]):
             cal.check(cache["layers"][l]["pooled"][rs], d[f"train_pooled_{l}"],
                       truth["layers"][l]["pooled"][rs], what=f"pooled {l}")
@@ -104,16 +105,16 @@ def test_train_step(case, dtype):
         if key.startswith("grad_"):
             name = key[len("grad_"):]
             if case.startswith("true_"):
-                assert_close(d[key], truth_out["grads"][name].reshape(d[key].shape), rtol=TRUE_SHAPE_GRAD_RTOL,
-                             what=key + " (golden vs fp64 oracle)", floor=floor)
-                assert_close(g[name].reshape(d[key].shape), truth_out["grads"][name].reshape(d[key].shape),
-                             rtol=TRUE_SHAPE_GRAD_RTOL, what=key, floor=floor)
+                assert_grad_true_shape(g[name].reshape(d[key].shape), d[key],
+                                       truth_out["grads"][name].reshape(d[key].shape), what=key, floor=floor)
             else:
                 assert_close(g[name].reshape(d[key].shape), d[key], rtol=gtol, what=key, floor=floor)
             checked += 1
         if key.startswith("gradnone_"):
             assert key[len("gradnone_"):] not in g or not cfg["learn_eps"]
     if "gradproj_r" in d:
+        if case.startswith("true_"):
+            gtol = TRUE_SHAPE_GRAD_RTOL
         W = g["disc.f_k.weight"][0].astype(np.float64)
         assert_close(W @ d["gradproj_r"], d["gradproj_Wr"], rtol=gtol, what="disc dW r")
         assert_close(d["gradproj_s"] @ W, d["gradproj_sW"], rtol=gtol, what="disc s dW")
