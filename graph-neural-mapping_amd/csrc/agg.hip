@@ -59,6 +59,7 @@ struct AggArgs {
     int ldsz, ld_dpool, ld_U, s_avg, n_batch;
     int ids_in_lds;            // narrow slices: the graph's column ids are staged in LDS (max_nnz given)
     int debug;                 // tuning only (GNM_AGG16_DEBUG): 1 no id loads, 2 no epilogue/store, 4 no combine
+    unsigned long long* stamps;   // tuning only: per-wave s_memtime stamps, [workgroup][16 waves][64] (gnm_debug_set_stamps)
     // forward prologue (agg16 only): the input is Z of the previous layer's last Linear; the tile load applies that
     // layer's outer BatchNorm + ReLU, writes the activation h (p_hout) and its graph readout (p_gf) on the way
     const float* p_scale; const float* p_shift;
@@ -620,39 +621,114 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
 //     transposing butterfly (12 shuffles per 4 rows instead of 32), after which
 //     quarter q owns row q: the epilogue and the 1-KiB output store use all 64 lanes.
 // ---------------------------------------------------------------------------------
-#define GNM_GROUP4(G)                                                          \
-    {                                                                          \
-        const f32x4 t0_ = lds_read16(row_bcast16<4 * G + 0>(valb) + subb);     \
-        const f32x4 t1_ = lds_read16(row_bcast16<4 * G + 1>(valb) + subb);     \
-        const f32x4 t2_ = lds_read16(row_bcast16<4 * G + 2>(valb) + subb);     \
-        const f32x4 t3_ = lds_read16(row_bcast16<4 * G + 3>(valb) + subb);     \
-        acc4(acc, t0_); acc4(acc, t1_); acc4(acc, t2_); acc4(acc, t3_);        \
-    }
-
+// One gather step of the 64-wide kernel reads 4 neighbour rows (one per 16-lane quarter).  Column ids arrive as
+// aligned PAIRS (one dword per lane = two consecutive ids of a 128-id window): the low halves of the 64 lanes and
+// the high halves each feed up to 16 steps, `ia` / `ib` being the LDS byte addresses they turned into.  A "double
+// step" S reads step S of both.  Blocks of 4 double steps keep 8 ds_read_b128 in flight (32 registers).
 #define GNM_RD(S) lds_read16(row_bcast16<S>(valb) + subb)
-#define GNM_PAIR(S0)                                                      \
-    {                                                                     \
-        const f32x4 p0_ = GNM_RD(S0), p1_ = GNM_RD(S0 + 1);               \
-        acc4(acc, p0_ + p1_);                                             \
+#define GNM_LO(S) lds_read16(row_bcast16<S>(ia) + subb)
+#define GNM_HI(S) lds_read16(row_bcast16<S>(ib) + subb)
+#define GNM_D1(S)                                                          \
+    {                                                                      \
+        const f32x4 a0_ = GNM_LO(S), b0_ = GNM_HI(S);                      \
+        acc4(acc, a0_ + b0_);                                              \
     }
-#define GNM_BLOCK8(H)                                                                                   \
-    {                                                                                                   \
-        const f32x4 a0_ = GNM_RD(8 * H + 0), a1_ = GNM_RD(8 * H + 1), a2_ = GNM_RD(8 * H + 2),           \
-                    a3_ = GNM_RD(8 * H + 3), a4_ = GNM_RD(8 * H + 4), a5_ = GNM_RD(8 * H + 5),           \
-                    a6_ = GNM_RD(8 * H + 6), a7_ = GNM_RD(8 * H + 7);                                     \
-        acc4(acc, (a0_ + a1_) + (a2_ + a3_));                                                           \
-        acc4(acc, (a4_ + a5_) + (a6_ + a7_));                                                           \
+#define GNM_D2(S)                                                                                   \
+    {                                                                                               \
+        const f32x4 a0_ = GNM_LO(S), b0_ = GNM_HI(S), a1_ = GNM_LO(S + 1), b1_ = GNM_HI(S + 1);     \
+        acc4(acc, (a0_ + b0_) + (a1_ + b1_));                                                       \
+    }
+#define GNM_D4W(S)                                                                                  \
+    {                                                                                               \
+        const f32x4 a0_ = GNM_LO(S), b0_ = GNM_HI(S), a1_ = GNM_LO(S + 1), b1_ = GNM_HI(S + 1),     \
+                    a2_ = GNM_LO(S + 2), b2_ = GNM_HI(S + 2), a3_ = GNM_LO(S + 3), b3_ = GNM_HI(S + 3); \
+        acc4(acc, ((a0_ + b0_) + (a1_ + b1_)) + ((a2_ + b2_) + (a3_ + b3_)));                       \
+    }
+// (the STATS kernel carries ~25 more live registers through the gather: 4 reads in flight per block there)
+#define GNM_D4(S)                      \
+    if constexpr (STATS) {             \
+        GNM_D2(S)                      \
+        GNM_D2((S) + 2)                \
+    } else {                           \
+        GNM_D4W(S)                     \
+    }
+// t in 0..3 double steps from step B on, exactly
+#define GNM_DTAIL(B, t)                       \
+    if ((t) >= 2) {                           \
+        GNM_D2(B)                             \
+        if ((t) >= 3) GNM_D1((B) + 2)         \
+    } else if ((t) >= 1) {                    \
+        GNM_D1(B)                             \
+    }
+// nd in 0..16 double steps, exactly
+#define GNM_DLADDER(nd)                                   \
+    if ((nd) >= 4) {                                      \
+        GNM_D4(0)                                         \
+        if ((nd) >= 8) {                                  \
+            GNM_D4(4)                                     \
+            if ((nd) >= 12) {                             \
+                GNM_D4(8)                                 \
+                if ((nd) >= 16) {                         \
+                    GNM_D4(12)                            \
+                } else {                                  \
+                    GNM_DTAIL(12, (nd) - 12)              \
+                }                                         \
+            } else {                                      \
+                GNM_DTAIL(8, (nd) - 8)                    \
+            }                                             \
+        } else {                                          \
+            GNM_DTAIL(4, (nd) - 4)                        \
+        }                                                 \
+    } else {                                              \
+        GNM_DTAIL(0, nd)                                  \
+    }
+// single-register forms (ids fetched in place beyond the 128-id window: degree > 128)
+#define GNM_S1(S) acc4(acc, GNM_RD(S));
+#define GNM_S2(S)                                                \
+    {                                                            \
+        const f32x4 p0_ = GNM_RD(S), p1_ = GNM_RD((S) + 1);      \
+        acc4(acc, p0_ + p1_);                                    \
+    }
+#define GNM_S4(S)                                                                                          \
+    {                                                                                                      \
+        const f32x4 t0_ = GNM_RD(S), t1_ = GNM_RD((S) + 1), t2_ = GNM_RD((S) + 2), t3_ = GNM_RD((S) + 3);  \
+        acc4(acc, (t0_ + t1_) + (t2_ + t3_));                                                              \
+    }
+#define GNM_S8(S)                                                                                          \
+    {                                                                                                      \
+        const f32x4 a0_ = GNM_RD(S), a1_ = GNM_RD((S) + 1), a2_ = GNM_RD((S) + 2), a3_ = GNM_RD((S) + 3),  \
+                    a4_ = GNM_RD((S) + 4), a5_ = GNM_RD((S) + 5), a6_ = GNM_RD((S) + 6), a7_ = GNM_RD((S) + 7); \
+        acc4(acc, ((a0_ + a1_) + (a2_ + a3_)) + ((a4_ + a5_) + (a6_ + a7_)));                              \
+    }
+// t in 0..8 steps from step B on, exactly
+#define GNM_STAIL(B, t)                              \
+    if ((t) >= 8) {                                  \
+        GNM_S8(B)                                    \
+    } else if ((t) >= 4) {                           \
+        GNM_S4(B)                                    \
+        if ((t) >= 6) {                              \
+            GNM_S2((B) + 4)                          \
+            if ((t) >= 7) GNM_S1((B) + 6)            \
+        } else if ((t) >= 5) {                       \
+            GNM_S1((B) + 4)                          \
+        }                                            \
+    } else if ((t) >= 2) {                           \
+        GNM_S2(B)                                    \
+        if ((t) >= 3) GNM_S1((B) + 2)                \
+    } else if ((t) >= 1) {                           \
+        GNM_S1(B)                                    \
+    }
+#define GNM_SLADDER(ns)                  \
+    if ((ns) > 8) {                      \
+        GNM_S8(0)                        \
+        GNM_STAIL(8, (ns) - 8)           \
+    } else {                             \
+        GNM_STAIL(0, ns)                 \
     }
 #define GNM_BLOCK16()                                                                                   \
     {                                                                                                   \
-        const f32x4 a0_ = GNM_RD(0), a1_ = GNM_RD(1), a2_ = GNM_RD(2), a3_ = GNM_RD(3), a4_ = GNM_RD(4),  \
-                    a5_ = GNM_RD(5), a6_ = GNM_RD(6), a7_ = GNM_RD(7), a8_ = GNM_RD(8), a9_ = GNM_RD(9),  \
-                    a10_ = GNM_RD(10), a11_ = GNM_RD(11), a12_ = GNM_RD(12), a13_ = GNM_RD(13),           \
-                    a14_ = GNM_RD(14), a15_ = GNM_RD(15);                                                 \
-        acc4(acc, (a0_ + a1_) + (a2_ + a3_));                                                           \
-        acc4(acc, (a4_ + a5_) + (a6_ + a7_));                                                           \
-        acc4(acc, (a8_ + a9_) + (a10_ + a11_));                                                         \
-        acc4(acc, (a12_ + a13_) + (a14_ + a15_));                                                       \
+        GNM_S8(0)                                                                                       \
+        GNM_S8(8)                                                                                       \
     }
 
 
@@ -670,9 +746,16 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     constexpr int FS = 64;
 #ifdef GNM_AGG16_TUNING       // tools/bench_agg.py ablations (GNM_AGG16_DEBUG); compiled out of the product kernel
     const int dbg = p.debug;
+    // in-kernel timeline (tools/agg_timeline.py): lane 0 of every wave drops s_memtime stamps at phase / group
+    // boundaries, where no LDS read is in flight anyway (s_memtime returns through lgkmcnt)
+#define GNM_STAMP(k)                                                                                          \
+    if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
+        p.stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime();
 #else
     constexpr int dbg = 0;
+#define GNM_STAMP(k)
 #endif
+    GNM_STAMP(0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* tile = reinterpret_cast<float4*>(smem);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -687,14 +770,86 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     const int32_t* drp = p.deg_rowptr + p.b_deg_off[b];
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
-    int* rp_s = reinterpret_cast<int*>(smem + (size_t)(n + 1) * (FS * 4));   // [n + 1] row offsets
     const bool vec_in = ((p.ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
     const bool vec_h = p.hfwd && ((p.ldh & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.hfwd) & 15) == 0);
     const bool prescale = p.backward && p.average;
     const int nwaves = nthreads >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = lane & 15;
+    const int q = lane >> 4;                                   // quarter of the wave
+    const int jlane = sub * 4 + q;                             // edge of a 64-chunk whose id this lane fetches
+    const unsigned jl2 = 2u * (unsigned)jlane;
+
+    // Row schedule: the rows are cut into GROUPS -- 4 consecutive rows each, except that the last `tail_rows` rows
+    // (about one per wave) are groups of ONE row -- and the groups are handed to the waves by TICKET (an LDS
+    // counter), three groups ahead of the gather:  ticket -> row bounds (global load) -> column ids (global load) ->
+    // gather, one pipeline stage per group.  A static deal left every wave idle for 16 % of the workgroup's time
+    // on average, waiting for the workgroup's slowest wave (in-kernel timeline, profiles/r02_agg_timeline.md): the
+    // waves see the same row count but not the same LDS service.  The first three tickets of a wave are fixed
+    // (wave, wave + W, wave + 2W), so the pipeline is primed without a round trip.
+    // The kernel that also reduces column statistics over the rows (STATS) keeps a STATIC deal instead -- full rounds
+    // of 4-row groups round-robin over the waves, the remainder as one short group per wave -- because those sums
+    // are accumulated per wave: with tickets their summation order, hence their last bits, would change from launch
+    // to launch (every reduction in this library has a fixed order; tests/test_gpu_model_parity.py
+    // test_run_to_run_determinism).  Row results themselves do not depend on which wave gathers them.
+    constexpr bool DYN = !STATS;
+    const int tail_rows = n >= nwaves + 3 ? nwaves + ((n - nwaves) & 3) : n;
+    const int n4 = (n - tail_rows) >> 2;                       // DYN: 4-row groups = tickets 0 .. n4-1; then single rows
+    const int nfull = n / (4 * nwaves);                        // static: full rounds, then one short group per wave
+    const int trem = n - nfull * 4 * nwaves;
+    const int tbase = trem / nwaves, textra = trem - tbase * nwaves;
+    const int tfirst = nfull * 4 * nwaves + wave * tbase + min(wave, textra);
+    const int trows = tbase + (wave < textra ? 1 : 0);
+    // tickets >= gtot: nothing left.  DYN: tickets number the groups of the graph; static: the groups of this wave
+    const int gtot = !p.y ? 0 : (DYN ? n4 + tail_rows : nfull + (trem > 0 ? 1 : 0));
+    int* const ticket = reinterpret_cast<int*>(smem + (size_t)(n + 1) * (FS * 4));     // LDS word behind the tile
+    // bounds of group t as a lane vector: lane i (0..4) = rowptr[first row + min(i, rows of the group)], read
+    // straight from global memory (a 1.6 KB array, L2-resident); an exhausted ticket yields an empty group at row 0
+    auto group_first = [&](int t) -> int {
+        if constexpr (DYN) return t < n4 ? 4 * t : (t < gtot ? 4 * n4 + (t - n4) : 0);
+        else return t < nfull ? 4 * (wave + t * nwaves) : (t < gtot ? tfirst : 0);
+    };
+    auto group_rows = [&](int t) -> int {
+        if constexpr (DYN) return t < n4 ? 4 : (t < gtot ? 1 : 0);
+        else return t < nfull ? 4 : (t < gtot ? trows : 0);
+    };
+    auto load_bounds = [&](int t) -> int { return rp[min(group_first(t) + min(lane & 7, group_rows(t)), n)]; };
+    // Column ids are requested FOUR rows (one group) ahead into a ring of 4 x 2 registers, as RAW values that are
+    // only turned into LDS addresses when their row becomes current.  vmcnt completes in issue order, stores
+    // included: with a one-row lookahead every wait for ids also waited for the output store issued just before
+    // them; now a wait only ever targets loads that are a whole group old.
+    // One request = one aligned DWORD per lane = two consecutive ids: the 64 lanes cover a 128-id window that starts
+    // at the row's first id rounded down to an even position of p.col (so any b_col_off works); a second request
+    // covers the next 128 ids (15 % of the rows of the 400-node benchmark graphs have more than 128 neighbours:
+    // fetched in place, each cost a dependent round trip and a drained queue).  The loads are unconditional (p.col
+    // stays readable 256 ids past the last block): a load inside a divergent branch would be drained at the join.
+    const long long colbase = p.b_col_off[b];
+    const uint16_t* clp = p.col + (colbase & ~1LL);            // 4-byte aligned (launcher checks p.col)
+    const int cpar = (int)(colbase & 1);
+    const unsigned jl4 = 4u * (unsigned)jlane;
+    auto load_pair = [&](int beg, unsigned window) -> unsigned {    // window w of the row that starts at local id `beg`
+        const unsigned a0 = (unsigned)(cpar + beg) & ~1u;
+        return *reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(clp) + ((a0 << 1) + 256u * window + jl4));
+    };
+    // The first two bounds vectors are requested here, unconditionally; the ring is filled by issue_ring() at exactly
+    // ONE place on every path through phase A -- after the first batch of tile loads is in flight and before
+    // anything is stored.  (A request that is pending on a path the compiler cannot rule out becomes a vmcnt(0)
+    // drain at its next use, inside the group loop.)
+    int tA = DYN ? wave : 0, tB = DYN ? wave + nwaves : 1, tC = DYN ? wave + 2 * nwaves : 2;
+    int bvA = load_bounds(tA), bvB = load_bounds(tB);
+    unsigned idw[4], idx[4];
+    auto issue_ring = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int beg = __builtin_amdgcn_readlane(bvA, r);
+            idw[r] = load_pair(beg, 0);
+            idx[r] = load_pair(beg, 1);
+        }
+    };
+    const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
 
     // ---- phase A ---------------------------------------------------------------
-    for (int i = tid; i <= n; i += nthreads) rp_s[i] = rp[i];
     double dot = 0.0;
     const int total = n * LPR;
     constexpr int UNR = 4;
@@ -718,6 +873,20 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
             csum.x += w.x; csum.y += w.y; csum.z += w.z; csum.w += w.w;
             tile[i] = w;
         };
+        if (base + (UNR - 1) * nthreads < total) {      // first batch, peeled: the id ring is requested behind its loads
+            float4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i = base + u * nthreads;
+                v[u] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + (i >> 4)) * p.ldx + 4 * (i & 15));
+            }
+            issue_ring();
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) emit(base + u * nthreads, v[u]);
+            base += nthreads * UNR;
+        } else {
+            issue_ring();
+        }
         for (; base + (UNR - 1) * nthreads < total; base += nthreads * UNR) {     // UNR x 16 B per thread in flight
             float4 v[UNR];
 #pragma unroll
@@ -747,41 +916,50 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         // readout partials: [nthreads] float4 behind the row offsets (the 64 threads of a column chunk)
         float4* rsum = reinterpret_cast<float4*>(smem + (((size_t)(n + 1) * (FS * 4) + (size_t)(n + 2) * 4 + 15) & ~(size_t)15));
         rsum[tid] = csum;
-    }
-    if (fast && !pro) {
-        // branch-free main part: UNR x 16 B (+ UNR x 16 B of hfwd) per thread in flight
-        for (; base + (UNR - 1) * nthreads < total; base += nthreads * UNR) {
-            float4 v[UNR], hh[UNR];
+    } else {
+    // branch-free main part: UNR x 16 B (+ UNR x 16 B of hfwd) per thread in flight; the id ring is requested
+    // behind the loads of the first batch
+    auto fast_batch = [&](int base, bool with_ring) {
+        float4 v[UNR], hh[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = base + u * nthreads;
+            const size_t off = (size_t)(row0 + (i >> 4)) * p.ldx + col0 + 4 * (i & 15);
+            v[u] = *reinterpret_cast<const float4*>(p.x + off);
+        }
+        if (dot_a) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int i = base + u * nthreads;
-                const size_t off = (size_t)(row0 + (i >> 4)) * p.ldx + col0 + 4 * (i & 15);
-                v[u] = *reinterpret_cast<const float4*>(p.x + off);
-            }
-            if (dot_a) {
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const int i = base + u * nthreads;
-                    const size_t off = (size_t)(row0 + (i >> 4)) * p.ldh + col0 + 4 * (i & 15);
-                    hh[u] = *reinterpret_cast<const float4*>(p.hfwd + off);
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    dot += (double)v[u].x * hh[u].x + (double)v[u].y * hh[u].y + (double)v[u].z * hh[u].z +
-                           (double)v[u].w * hh[u].w;
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int i = base + u * nthreads;
-                float4 w = v[u];
-                if (prescale) {
-                    const int r = i >> 4;
-                    const float d = (float)(drp[r + 1] - drp[r] + p.self_loop);
-                    w.x /= d; w.y /= d; w.z /= d; w.w /= d;
-                }
-                tile[i] = w;
+                const size_t off = (size_t)(row0 + (i >> 4)) * p.ldh + col0 + 4 * (i & 15);
+                hh[u] = *reinterpret_cast<const float4*>(p.hfwd + off);
             }
         }
+        if (with_ring) issue_ring();
+        if (dot_a) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                dot += (double)v[u].x * hh[u].x + (double)v[u].y * hh[u].y + (double)v[u].z * hh[u].z +
+                       (double)v[u].w * hh[u].w;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = base + u * nthreads;
+            float4 w = v[u];
+            if (prescale) {
+                const int r = i >> 4;
+                const float d = (float)(drp[r + 1] - drp[r] + p.self_loop);
+                w.x /= d; w.y /= d; w.z /= d; w.w /= d;
+            }
+            tile[i] = w;
+        }
+    };
+    if (fast && base + (UNR - 1) * nthreads < total) {
+        fast_batch(base, true);
+        base += nthreads * UNR;
+        for (; base + (UNR - 1) * nthreads < total; base += nthreads * UNR) fast_batch(base, false);
+    } else {
+        issue_ring();
     }
     for (; base < total; base += nthreads) {      // tail, and the generic (unaligned / partial-width) path
         const int i = base;
@@ -816,8 +994,36 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         }
         tile[i] = w;
     }
+    }
+    // fused BatchNorm-backward statistics of the layer below (STATS): per-lane column chunk `sub` (requested in
+    // front of the drain below, like everything else the group loop finds already in registers)
+    float4 ss1 = make_float4(0.f, 0.f, 0.f, 0.f), ss2 = ss1, s_pb = ss1, s_ub = ss1;
+    float4 lsc = ss1, lsh = ss1, lmu = ss1;
+    if constexpr (STATS) {
+        lsc = *reinterpret_cast<const float4*>(p.s_scale + 4 * sub);
+        lsh = *reinterpret_cast<const float4*>(p.s_shift + 4 * sub);
+        lmu = *reinterpret_cast<const float4*>(p.s_mean + 4 * sub);      // (rstd multiplies the column sums at the end)
+        if (p.s_dpool) {
+            s_pb = *reinterpret_cast<const float4*>(p.s_dpool + (size_t)b * p.ld_dpool + 4 * sub);
+            if (p.s_avg) {
+                const float w = 1.0f / (float)n;
+                s_pb.x *= w; s_pb.y *= w; s_pb.z *= w; s_pb.w *= w;
+            }
+        }
+        if (p.s_dsc1) s_ub = *reinterpret_cast<const float4*>(p.s_U + (size_t)b * p.ld_U + 4 * sub);
+    }
+
     if (tid < LPR) tile[n * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Drain this wave's vector-memory queue HERE, once per graph, in front of the barrier (where all but the last
+    // wave wait anyway): the group loop below then starts from a known-empty queue and its waits come out as the
+    // exact counted vmcnt(3) per row.  Without it the compiler merges the several phase-A paths into "something may
+    // be pending" and drains the queue -- output stores included -- at the top of every group.
+    if (DYN && tid == 0) *ticket = 3 * nwaves;   // tickets 0 .. 3W-1 are the fixed first three of every wave
+    GNM_STAMP(1)
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0); expcnt / lgkmcnt left alone
+    GNM_STAMP(2)
     __syncthreads();
+    GNM_STAMP(3)
     if (pro && p.p_gf && tid < LPR) {
         // graph readout of the activation just formed (graphcnn.py:229), partials combined in thread order
         const float4* rsum = reinterpret_cast<const float4*>(smem + (((size_t)(n + 1) * (FS * 4) + (size_t)(n + 2) * 4 + 15) & ~(size_t)15));
@@ -831,45 +1037,19 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     }
 
     // ---- phase B ---------------------------------------------------------------
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = lane & 15;
-    const int q = lane >> 4;                                   // quarter of the wave
     const unsigned subb = lds_base + (unsigned)sub * 16u;
-    const int jlane = sub * 4 + q;                             // edge of a 64-chunk this lane fetches
     const unsigned zero_row_b = (unsigned)n * (FS * 4);
-    const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
     const bool vec_out = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
-    const int ngroups = p.y ? (n + 3) >> 2 : 0;
-    const bool need_deg = !p.backward && p.average;
+    const bool vec_full = vec_out && (col0 + FS <= p.F);       // this slice is full width and 16-byte addressable
+    const bool need_deg = !STATS && !p.backward && p.average;  // (STATS launches are backward launches)
     const int qm1 = -(q & 1), qm2 = -(q >> 1);               // all-ones masks selecting this lane's quarter
-    // fused BatchNorm-backward statistics of the layer below (STATS): per-lane column chunk `sub`
-    float4 ss1 = make_float4(0.f, 0.f, 0.f, 0.f), ss2 = ss1, s_pb = ss1, s_ub = ss1;
-    float4 lsc = ss1, lsh = ss1, lmu = ss1, lrs = ss1;
-    if constexpr (STATS) {
-        lsc = *reinterpret_cast<const float4*>(p.s_scale + 4 * sub);
-        lsh = *reinterpret_cast<const float4*>(p.s_shift + 4 * sub);
-        lmu = *reinterpret_cast<const float4*>(p.s_mean + 4 * sub);
-        lrs = *reinterpret_cast<const float4*>(p.s_rstd + 4 * sub);
-        if (p.s_dpool) {
-            s_pb = *reinterpret_cast<const float4*>(p.s_dpool + (size_t)b * p.ld_dpool + 4 * sub);
-            if (p.s_avg) {
-                const float w = 1.0f / (float)n;
-                s_pb.x *= w; s_pb.y *= w; s_pb.z *= w; s_pb.w *= w;
-            }
-        }
-        if (p.s_dsc1) s_ub = *reinterpret_cast<const float4*>(p.s_U + (size_t)b * p.ld_U + 4 * sub);
-    }
-
-    // Groups of 4 consecutive rows are dealt round-robin to the waves (group g -> wave g % nwaves).
-    // No LDS round trip sits on the per-row critical path: under load the LDS queue is ~1000
-    // cycles deep, so row bounds come from a lane vector loaded once per 8 groups
-    // (v_readlane), column ids are fetched one row ahead, and the 4-row combine below is
-    // pure VALU (v_permlane32_swap / v_permlane16_swap).
+    // No LDS round trip sits on the per-row critical path: under load the LDS queue is ~1000 cycles deep, so row
+    // bounds come from the lane vector (v_readlane), column ids arrive a group ahead, and the 4-row combine below
+    // is pure VALU (v_permlane32_swap / v_permlane16_swap).
     if (dbg & 8) {   // tuning: the micro-benchmark's steady-state loop, same step count (2 x 16 per row)
         unsigned valb = (unsigned)((lane * 37 + 11) % max(n, 1)) * (FS * 4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int g = wave; g < ngroups; g += nwaves)
+        for (int g = 0; g < (n + 4 * nwaves - 1) / (4 * nwaves); ++g)
             for (int r = 0; r < 8; ++r) {
                 GNM_BLOCK16()
                 valb ^= 256;
@@ -877,184 +1057,180 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         if (acc.x == 12345.678f) p.y[0] = acc.y + acc.z + acc.w;
         return;
     }
-    // Row schedule: full rounds deal groups of 4 consecutive rows round-robin (group g -> wave g % nwaves); the
-    // rows left over after the last full round (< 4 * nwaves) are dealt as ONE short group per wave of
-    // floor/ceil(rem / nwaves) rows, so every wave gathers the same number of rows +-1 (n = 400 on 16 waves: 6
-    // groups of 4 + 1 row each; dealing the last 4 groups whole left 12 of 16 waves idle for a seventh of the gather).
-    const int nfull = n / (4 * nwaves);
-    const int tail0 = nfull * 4 * nwaves;
-    const int trem = n - tail0;
-    const int tbase = trem / nwaves, textra = trem - tbase * nwaves;
-    const int tfirst = tail0 + wave * tbase + min(wave, textra);
-    const int trows = tbase + (wave < textra ? 1 : 0);
-    const int ngw = ngroups ? nfull + (trem > 0 ? 1 : 0) : 0;      // groups per wave (the short one may be empty)
-    for (int k0 = 0; k0 < ngw; k0 += 8) {
-        int rpv = 0;
-        {
-            const int gi = k0 + (lane >> 3);
-            const bool full = gi < nfull;
-            const int first = full ? 4 * (wave + gi * nwaves) : tfirst;
-            const int row = min(first + min(lane & 7, full ? 4 : trows), n);
-            if (gi < ngw) rpv = rp_s[row];
+    int kk = 0;
+    while (tA < gtot) {                                                        // wave-uniform
+        GNM_STAMP(4 + 5 * min(kk, 10))
+        // ticket for the group three ahead (one LDS atomic by lane 0, read at the bottom of this iteration, by
+        // which time every LDS operation issued before it has long returned), and its predecessor's bounds
+        int tD = tC + 1;
+        if constexpr (DYN) {
+            if (lane == 0) tD = atomicAdd(ticket, 1);
         }
-        const int ng = min(ngw - k0, 8);                                  // groups of this wave in this block
-        int nbeg = __builtin_amdgcn_readlane(rpv, 0), nend = __builtin_amdgcn_readlane(rpv, 1);
-        // Column ids are prefetched one row ahead as RAW values and only turned into LDS
-        // addresses when the row becomes current, so the wait is a counted vmcnt at the use.
-        // The loads are unconditional (the arena keeps >= 128 readable ids past the last
-        // block): a load inside a divergent branch would be drained (vmcnt(0)) at the join.
-        const unsigned jl2 = 2u * (unsigned)jlane;
-        unsigned nra = load_id(cl, 2u * (unsigned)nbeg + jl2), nrb = load_id(cl, 2u * (unsigned)nbeg + 128u + jl2);
-        for (int kk = 0; kk < ng; ++kk) {
-            const bool gfull = k0 + kk < nfull;                                // wave-uniform
-            const int grows = gfull ? 4 : trows;                               // rows of this group (quarter q owns row q)
-            // this quarter's own row (for the self term): read it NOW, ahead of the gather, so it
-            // is not a dependent LDS round trip behind ~256 queued reads in the epilogue
-            const int v = (gfull ? 4 * (wave + (k0 + kk) * nwaves) : tfirst) + q;
-            const float4 self = tile[min(v, n) * LPR + sub];
-            float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
-            float dsc_v = 0.f;
-            if constexpr (STATS) {     // requested ahead of the gather, consumed in the epilogue
-                const int vc = row0 + min(v, n - 1);
-                zrow = *reinterpret_cast<const float4*>(p.sZ + (size_t)vc * p.ldsz + 4 * sub);
-                if (p.s_dsc1) dsc_v = p.s_dsc1[vc];
-            }
-            // degree of row v (forward "average" only) from the rowptr lane vector (no LDS): 5 readlanes, then a
-            // branch-free per-quarter select (written as a ?: chain it compiled to ~40 exec-mask/branch
-            // instructions per group, on every launch)
-            int degv = 0;
-            if (need_deg) {                                    // wave-uniform
-                const int b0 = __builtin_amdgcn_readlane(rpv, 8 * kk), b1 = __builtin_amdgcn_readlane(rpv, 8 * kk + 1),
-                          b2 = __builtin_amdgcn_readlane(rpv, 8 * kk + 2), b3 = __builtin_amdgcn_readlane(rpv, 8 * kk + 3),
-                          b4 = __builtin_amdgcn_readlane(rpv, 8 * kk + 4);
-                const int d0 = b1 - b0, d1 = b2 - b1, d2 = b3 - b2, d3 = b4 - b3;
-                const int lo = (d0 & ~qm1) | (d1 & qm1), hi = (d2 & ~qm1) | (d3 & qm1);
-                degv = (lo & ~qm2) | (hi & qm2);
-            }
-            float4 racc[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int beg = nbeg, end = nend;
-                const unsigned ra = nra, rb = nrb;
-                // issue the loads of the row after this one
-                const int tl = (r < 3) ? (8 * kk + r + 1) : (8 * (kk + 1));
-                if (r < 3 || kk + 1 < ng) {                   // wave-uniform
-                    nbeg = __builtin_amdgcn_readlane(rpv, tl);
-                    nend = __builtin_amdgcn_readlane(rpv, tl + 1);
-                } else {
-                    nend = nbeg;                               // nothing follows: an empty row at a valid address
-                }
-                if (!(dbg & 1)) {
-                    nra = load_id(cl, 2u * (unsigned)nbeg + jl2);
-                    nrb = load_id(cl, 2u * (unsigned)nbeg + 128u + jl2);
-                }
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                int cnt = end - beg;
-                int e0 = beg;
-                const unsigned ia = (jlane < cnt) ? ra * (FS * 4) : zero_row_b;
-                const unsigned ib = (jlane + 64 < cnt) ? rb * (FS * 4) : zero_row_b;
-                unsigned valb = ia;
-                while (cnt > 0) {
-                    const int c64 = min(cnt, 64);
-                    const int steps = (c64 + 3) >> 2;          // wave-uniform
-                    // 16 ds_read_b128 in flight per block; the STATS variant needs the 32 registers and uses
-                    // two 8-deep blocks (measured within noise of 16-deep at 16 waves/CU)
-                    // (13 or 14 steps -- half of the second chunks at mean degree 119 -- stop at 14 reads, not 16)
-                    if (steps > 14 && !STATS) {
-                        GNM_BLOCK16()
-                    } else if (steps > 8) {
-                        GNM_BLOCK8(0)
-                        if (steps > 14) {
-                            GNM_BLOCK8(1)
-                        } else {
-                            GNM_GROUP4(2)
-                            if (steps > 12) GNM_PAIR(12)
-                        }
-                    } else if (steps > 4) {
-                        GNM_BLOCK8(0)
-                    } else {
-                        GNM_GROUP4(0)
-                    }
-                    cnt -= 64;
-                    e0 += 64;
-                    if (cnt <= 0) break;
-                    if (e0 == beg + 64) {
-                        valb = ib;                             // second chunk was prefetched
-                    } else {                                   // degree > 128: fetch in place
-                        const unsigned rc = load_id(cl, 2u * (unsigned)e0 + jl2);
-                        valb = (jlane < cnt) ? rc * (FS * 4) : zero_row_b;
-                    }
-                }
-                racc[r] = acc;
-            }
-            // transposing combine: afterwards quarter q holds the full sum of row 4g + q
-            float4 tot;
-            if (dbg & 4) {
-                tot = racc[0]; acc4(tot, racc[1]); acc4(tot, racc[2]); acc4(tot, racc[3]);
+        const int bvC = load_bounds(tC);
+        const int gfirst = group_first(tA);
+        const int grows = group_rows(tA);                                      // rows of this group (quarter q owns row q)
+        // this quarter's own row (for the self term): read it NOW, ahead of the gather, so it
+        // is not a dependent LDS round trip behind ~256 queued reads in the epilogue
+        const int v = gfirst + q;
+        const float4 self = tile[min(v, n) * LPR + sub];
+        // "average" backward: the tile holds x / deg, the (1 + eps) self term needs x itself -- requested here,
+        // ahead of the gather (a load issued in the epilogue is waited for at once, which drains the whole queue)
+        float4 xself = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (prescale && !p.self_loop) {                                  // wave-uniform
+            const int cc = col0 + 4 * sub;
+            const float* src = p.x + (size_t)(row0 + min(v, n - 1)) * p.ldx + cc;
+            if (vec_in && col0 + FS <= p.F) {
+                xself = *reinterpret_cast<const float4*>(src);
             } else {
-                const float4 t02 = swap_add32(racc[0], racc[2]);   // lanes 0-31: row 0, lanes 32-63: row 2
-                const float4 t13 = swap_add32(racc[1], racc[3]);
-                tot = swap_add16(t02, t13);
-            }
-
-            if (dbg & 2) {
-                if (tot.x == 12345.678f) p.y[0] = tot.y + tot.z + tot.w + self.x;   // keep values live
-            } else if (q < grows) {
-                if (p.self_loop) acc4(tot, self);
-                if (!p.backward && p.average) {
-                    const float d = (float)(degv + p.self_loop);   // 0/0 -> NaN as in the reference
-                    tot.x /= d; tot.y /= d; tot.z /= d; tot.w /= d;
-                }
-                const int cc = col0 + 4 * sub;
-                if (!p.self_loop) {
-                    float4 sb = self;
-                    if (prescale) {
-                        const float* src = p.x + (size_t)(row0 + v) * p.ldx + cc;
-                        sb.x = (cc + 0 < p.F) ? src[0] : 0.f;
-                        sb.y = (cc + 1 < p.F) ? src[1] : 0.f;
-                        sb.z = (cc + 2 < p.F) ? src[2] : 0.f;
-                        sb.w = (cc + 3 < p.F) ? src[3] : 0.f;
-                    }
-                    tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
-                    if constexpr (STATS) {
-                        if (p.deps_partial && !p.hfwd) {
-                            // d eps += dpooled[v] . h[v], h = relu(bn_lo(Z[v])) recomputed as the forward formed it
-                            const float hx = fmaxf(zrow.x * lsc.x + lsh.x, 0.f), hy = fmaxf(zrow.y * lsc.y + lsh.y, 0.f);
-                            const float hz = fmaxf(zrow.z * lsc.z + lsh.z, 0.f), hw = fmaxf(zrow.w * lsc.w + lsh.w, 0.f);
-                            dot += (double)(sb.x * hx + sb.y * hy) + (double)(sb.z * hz + sb.w * hw);
-                        }
-                    }
-                }
-                if constexpr (STATS) {
-                    // total gradient at this layer output = aggregation backward + readout + discriminator terms
-                    tot.x += s_pb.x + dsc_v * s_ub.x; tot.y += s_pb.y + dsc_v * s_ub.y;
-                    tot.z += s_pb.z + dsc_v * s_ub.z; tot.w += s_pb.w + dsc_v * s_ub.w;
-                    if (p.s_dsc1 && row0 + v < p.n_batch) {     // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
-                        const int gq = p.s_inv_perm[row0 + v];
-                        const float s2 = p.s_s2sum[gq];
-                        const float4 uq = *reinterpret_cast<const float4*>(p.s_U + (size_t)gq * p.ld_U + 4 * sub);
-                        tot.x += s2 * uq.x; tot.y += s2 * uq.y; tot.z += s2 * uq.z; tot.w += s2 * uq.w;
-                    }
-                    if (!(zrow.x * lsc.x + lsh.x > 0.f)) tot.x = 0.f;
-                    if (!(zrow.y * lsc.y + lsh.y > 0.f)) tot.y = 0.f;
-                    if (!(zrow.z * lsc.z + lsh.z > 0.f)) tot.z = 0.f;
-                    if (!(zrow.w * lsc.w + lsh.w > 0.f)) tot.w = 0.f;
-                    ss1.x += tot.x; ss1.y += tot.y; ss1.z += tot.z; ss1.w += tot.w;
-                    ss2.x += tot.x * ((zrow.x - lmu.x) * lrs.x); ss2.y += tot.y * ((zrow.y - lmu.y) * lrs.y);
-                    ss2.z += tot.z * ((zrow.z - lmu.z) * lrs.z); ss2.w += tot.w * ((zrow.w - lmu.w) * lrs.w);
-                }
-                float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
-                if (vec_out && cc + 3 < p.F) {
-                    *reinterpret_cast<float4*>(dst) = tot;
-                } else {
-                    if (cc + 0 < p.F) dst[0] = tot.x;
-                    if (cc + 1 < p.F) dst[1] = tot.y;
-                    if (cc + 2 < p.F) dst[2] = tot.z;
-                    if (cc + 3 < p.F) dst[3] = tot.w;
-                }
+                xself.x = (cc + 0 < p.F) ? src[0] : 0.f;
+                xself.y = (cc + 1 < p.F) ? src[1] : 0.f;
+                xself.z = (cc + 2 < p.F) ? src[2] : 0.f;
+                xself.w = (cc + 3 < p.F) ? src[3] : 0.f;
             }
         }
+        float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dsc_v = 0.f;
+        if constexpr (STATS) {     // requested ahead of the gather, consumed in the epilogue
+            const int vc = row0 + min(v, n - 1);
+            zrow = *reinterpret_cast<const float4*>(p.sZ + (size_t)vc * p.ldsz + 4 * sub);
+            if (p.s_dsc1) dsc_v = p.s_dsc1[vc];
+        }
+        // row bounds of this group
+        const int b0 = __builtin_amdgcn_readlane(bvA, 0), b1 = __builtin_amdgcn_readlane(bvA, 1),
+                  b2 = __builtin_amdgcn_readlane(bvA, 2), b3 = __builtin_amdgcn_readlane(bvA, 3),
+                  b4 = __builtin_amdgcn_readlane(bvA, 4);
+        // degree of row v (forward "average" only): a branch-free per-quarter select (written as a ?: chain it
+        // compiled to ~40 exec-mask/branch instructions per group, on every launch)
+        int degv = 0;
+        if (need_deg) {                                    // wave-uniform
+            const int d0 = b1 - b0, d1 = b2 - b1, d2 = b3 - b2, d3 = b4 - b3;
+            const int lo = (d0 & ~qm1) | (d1 & qm1), hi = (d2 & ~qm1) | (d3 & qm1);
+            degv = (lo & ~qm2) | (hi & qm2);
+        }
+        float4 racc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int beg = r == 0 ? b0 : (r == 1 ? b1 : (r == 2 ? b2 : b3));
+            const int end = r == 0 ? b1 : (r == 1 ? b2 : (r == 2 ? b3 : b4));
+            const int cnt = end - beg;
+            // This row's first window becomes LDS addresses FIRST (the raw value is then dead), and only then is
+            // its ring slot refilled: written the other way round the compiler parks all four old values in copies
+            // at the top of the group, which needs every outstanding request -- and the store -- complete.
+            // Window position of an id = 2 * jlane (+ 1 for the high half); the row's ids sit at positions
+            // o .. o + cnt - 1 for o = parity of the row start; the rest read the zero row.
+            const int o = (cpar + beg) & 1;
+            const unsigned wl = 2u * (unsigned)jlane - (unsigned)o;
+            unsigned ia = (wl < (unsigned)cnt) ? ((idw[r] & 0xffffu) << 8) : zero_row_b;
+            unsigned ib = (wl + 1u < (unsigned)cnt) ? ((idw[r] >> 16) << 8) : zero_row_b;
+            // (compiler barrier: keeps the two address computations above the refill -- left alone, they are sunk
+            // into the gather below it)
+            asm volatile("" : "+v"(ia), "+v"(ib) : : "memory");
+            // the windows of row r of the NEXT group (an exhausted ticket: requests at a valid address whose
+            // results are never used)
+            const int nbeg = __builtin_amdgcn_readlane(bvB, r);
+            if (!(dbg & 1)) idw[r] = load_pair(nbeg, 0);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cnt > 0) {                                 // wave-uniform
+                const int used = cnt + o;                            // window positions [o, used) hold this row's ids
+                const int nd = min((used + 7) >> 3, 16);            // double steps (4 low + 4 high ids each)
+                GNM_DLADDER(nd)
+                if (used > 128) {                                    // second window (wave-uniform)
+                    const unsigned wl2 = wl + 128u;
+                    unsigned ia2 = (wl2 < (unsigned)cnt) ? ((idx[r] & 0xffffu) << 8) : zero_row_b;
+                    unsigned ib2 = (wl2 + 1u < (unsigned)cnt) ? ((idx[r] >> 16) << 8) : zero_row_b;
+                    asm volatile("" : "+v"(ia2), "+v"(ib2) : : "memory");
+                    {
+                        const unsigned ia = ia2, ib = ib2;
+                        const int nd2 = min((used - 128 + 7) >> 3, 16);
+                        GNM_DLADDER(nd2)
+                    }
+                    // degree beyond both windows (> 256 - o ids): 64 ids at a time, fetched in place
+                    for (int e0 = beg + 256 - o; e0 < end; e0 += 64) {
+                        const int c64 = min(end - e0, 64);
+                        const unsigned rc = load_id(cl, 2u * (unsigned)e0 + jl2);
+                        const unsigned valb = (jlane < c64) ? rc * (FS * 4) : zero_row_b;
+                        const int ns = (c64 + 3) >> 2;
+                        GNM_SLADDER(ns)
+                    }
+                }
+            }
+            if (!(dbg & 1)) idx[r] = load_pair(nbeg, 1);
+            racc[r] = acc;
+        }
+        GNM_STAMP(5 + 5 * min(kk, 10))
+        // transposing combine: afterwards quarter q holds the full sum of row q of the group
+        float4 tot;
+        if (dbg & 4) {
+            tot = racc[0]; acc4(tot, racc[1]); acc4(tot, racc[2]); acc4(tot, racc[3]);
+        } else {
+            const float4 t02 = swap_add32(racc[0], racc[2]);   // lanes 0-31: row 0, lanes 32-63: row 2
+            const float4 t13 = swap_add32(racc[1], racc[3]);
+            tot = swap_add16(t02, t13);
+        }
+        GNM_STAMP(6 + 5 * min(kk, 10))
+
+        if (dbg & 2) {
+            if (tot.x == 12345.678f) p.y[0] = tot.y + tot.z + tot.w + self.x;   // keep values live
+        } else if (q < grows) {
+            if (p.self_loop) acc4(tot, self);
+            if (need_deg) {
+                const float d = (float)(degv + p.self_loop);   // 0/0 -> NaN as in the reference
+                tot.x /= d; tot.y /= d; tot.z /= d; tot.w /= d;
+            }
+            const int cc = col0 + 4 * sub;
+            if (!p.self_loop) {
+                const float4 sb = prescale ? xself : self;
+                tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
+                if constexpr (STATS) {
+                    if (p.deps_partial && !p.hfwd) {
+                        // d eps += dpooled[v] . h[v], h = relu(bn_lo(Z[v])) recomputed as the forward formed it
+                        const float hx = fmaxf(zrow.x * lsc.x + lsh.x, 0.f), hy = fmaxf(zrow.y * lsc.y + lsh.y, 0.f);
+                        const float hz = fmaxf(zrow.z * lsc.z + lsh.z, 0.f), hw = fmaxf(zrow.w * lsc.w + lsh.w, 0.f);
+                        dot += (double)(sb.x * hx + sb.y * hy) + (double)(sb.z * hz + sb.w * hw);
+                    }
+                }
+            }
+            if constexpr (STATS) {
+                // total gradient at this layer output = aggregation backward + readout + discriminator terms
+                tot.x += s_pb.x + dsc_v * s_ub.x; tot.y += s_pb.y + dsc_v * s_ub.y;
+                tot.z += s_pb.z + dsc_v * s_ub.z; tot.w += s_pb.w + dsc_v * s_ub.w;
+                if (p.s_dsc1 && row0 + v < p.n_batch) {     // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
+                    const int gq = p.s_inv_perm[row0 + v];
+                    const float s2 = p.s_s2sum[gq];
+                    const float4 uq = *reinterpret_cast<const float4*>(p.s_U + (size_t)gq * p.ld_U + 4 * sub);
+                    tot.x += s2 * uq.x; tot.y += s2 * uq.y; tot.z += s2 * uq.z; tot.w += s2 * uq.w;
+                }
+                if (!(zrow.x * lsc.x + lsh.x > 0.f)) tot.x = 0.f;
+                if (!(zrow.y * lsc.y + lsh.y > 0.f)) tot.y = 0.f;
+                if (!(zrow.z * lsc.z + lsh.z > 0.f)) tot.z = 0.f;
+                if (!(zrow.w * lsc.w + lsh.w > 0.f)) tot.w = 0.f;
+                ss1.x += tot.x; ss1.y += tot.y; ss1.z += tot.z; ss1.w += tot.w;
+                ss2.x += tot.x * (zrow.x - lmu.x); ss2.y += tot.y * (zrow.y - lmu.y);
+                ss2.z += tot.z * (zrow.z - lmu.z); ss2.w += tot.w * (zrow.w - lmu.w);
+            }
+            GNM_STAMP(7 + 5 * min(kk, 10))
+            float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
+            if (vec_full) {     // wave-uniform: ONE 16-byte store per lane (a per-lane condition here was
+                                // if-converted into a 12-byte + a 4-byte masked store on every launch)
+                // (a plain float4 store here is merged by the optimiser with the scalar stores of the other
+                //  branch into a 12-byte + a 4-byte store; the streaming flavour cannot be: ONE
+                //  global_store_dwordx4 nt.  The row is written once and next read by another kernel.)
+                const f32x4 t4 = {tot.x, tot.y, tot.z, tot.w};
+                __builtin_nontemporal_store(t4, reinterpret_cast<f32x4*>(dst));
+            } else {
+                if (cc + 0 < p.F) dst[0] = tot.x;
+                if (cc + 1 < p.F) dst[1] = tot.y;
+                if (cc + 2 < p.F) dst[2] = tot.z;
+                if (cc + 3 < p.F) dst[3] = tot.w;
+            }
+        }
+        GNM_STAMP(8 + 5 * min(kk, 10))
+        // advance the pipeline
+        tA = tB; tB = tC; tC = __builtin_amdgcn_readfirstlane(tD);
+        bvA = bvB; bvB = bvC;
+        ++kk;
     }
+    GNM_STAMP(63)
 
     if constexpr (STATS) {     // column sums: the 4 quarters of a wave, then the waves, in a fixed order
         __syncthreads();
@@ -1075,6 +1251,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
             const int which = tid >> 6, col = tid & 63;
             double sum = 0.0;
             for (int w = 0; w < nwaves; ++w) sum += sred[(w * 2 + which) * 64 + col];
+            if (which) sum *= (double)p.s_rstd[col];      // sum G (Z - mean) -> sum G xhat
             p.s_partial[((size_t)blockIdx.x * 2 + which) * 64 + col] = sum;
         }
         __syncthreads();
@@ -1094,7 +1271,18 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
     }
 }
 
-static int launch_agg16(const AggArgs& a, int B, int n_max, hipStream_t stream) {
+#ifdef GNM_AGG16_TUNING
+static unsigned long long* g_agg16_stamps = nullptr;
+extern "C" void gnm_debug_set_stamps(void* p) { g_agg16_stamps = reinterpret_cast<unsigned long long*>(p); }
+#endif
+
+static int launch_agg16(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
+    AggArgs a = a0;
+#ifdef GNM_AGG16_TUNING
+    a.stamps = g_agg16_stamps;
+#else
+    a.stamps = nullptr;
+#endif
     size_t lds = (size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 16;
     if (a.p_scale) lds += 16 + (size_t)1024 * 16;     // forward prologue: readout partials of up to 1024 threads
     GNM_ALLOW_FULL_LDS(&gnm_agg16_kernel<false>);
@@ -1104,6 +1292,7 @@ static int launch_agg16(const AggArgs& a, int B, int n_max, hipStream_t stream) 
     else if (lds <= 48 * 1024) threads = 512;
     static const int env_threads = gnm_env_int("GNM_AGG16_THREADS", 0);   // tuning knob for tools/bench_agg.py
     if (env_threads >= 64 && env_threads <= 1024 && (env_threads & 63) == 0) threads = env_threads;
+    if (reinterpret_cast<uintptr_t>(a.col) & 3) return GNM_ERR_UNSUPPORTED;     // column ids are fetched as aligned pairs
     if (a.sZ)
         hipLaunchKernelGGL(gnm_agg16_kernel<true>, dim3(B * a.nslices), dim3(threads), lds, stream, a);
     else

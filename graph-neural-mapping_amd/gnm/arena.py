@@ -44,7 +44,10 @@ class Batch:
     """What the kernels need to know about one batch of graphs (all on the device)."""
 
     __slots__ = ("B", "N", "n_max", "n_min", "nnz_max", "arena", "node_off", "rp_off", "col_off", "t_rp_off",
-                 "t_col_off", "gids", "node_off_host", "symmetric")
+                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base")
+    # feat_base: int64 [B], first row of each graph's node features in the arena's feature buffer.  Part of the
+    # batch (not looked up in the arena's tables at use): a captured hipGraph replays the lookup's kernels with the
+    # table tensor of capture time, which is freed as soon as another graph is added to the arena.
 
     @property
     def equal_n(self):
@@ -200,7 +203,12 @@ class GraphArena:
                                     tcol=t(self.t_col_off, torch.int64), feat=t(self.feat_off, torch.int64),
                                     n_host=np.asarray(self.n, dtype=np.int64),
                                     nnz_host=np.asarray(self.nnz, dtype=np.int64),
-                                    sym_host=np.asarray(self.sym, dtype=bool))
+                                    sym_host=np.asarray(self.sym, dtype=bool),
+                                    rp_host=np.asarray(self.rp_off, dtype=np.int64),
+                                    col_host=np.asarray(self.col_off, dtype=np.int64),
+                                    trp_host=np.asarray(self.t_rp_off, dtype=np.int64),
+                                    tcol_host=np.asarray(self.t_col_off, dtype=np.int64),
+                                    feat_host=np.asarray(self.feat_off, dtype=np.int64))
         return self._dev_tables
 
     # ------------------------------------------------------------------ batches
@@ -227,6 +235,7 @@ class GraphArena:
         b.node_off = torch.as_tensor(node_off_host.astype(np.int32)).to(self.device, non_blocking=True)
         b.rp_off = tb["rp"][gd]
         b.col_off = tb["col"][gd]
+        b.feat_base = tb["feat"][gd]
         b.symmetric = bool(tb["sym_host"][gh].all())
         if b.symmetric:
             b.t_rp_off, b.t_col_off = b.rp_off, b.col_off
@@ -235,12 +244,12 @@ class GraphArena:
         return b
 
     def _feature_rows(self, batch):
-        tb = self._tables()
         if batch.equal_n:
-            base = tb["feat"][batch.gids]
+            base = batch.feat_base
             return (base[:, None] + torch.arange(batch.n_max, device=self.device)[None, :]).reshape(-1)
+        tb = self._tables()
         ns = tb["n"][batch.gids]
-        base = torch.repeat_interleave(tb["feat"][batch.gids], ns)
+        base = torch.repeat_interleave(batch.feat_base, ns)
         start = torch.repeat_interleave(torch.as_tensor(batch.node_off_host[:-1], device=self.device), ns)
         return base + (torch.arange(batch.N, device=self.device) - start)
 
@@ -288,6 +297,13 @@ class GraphArena:
         store["graphs"] = G
         return store["buf"]
 
+    def refresh_agg0(self, average, self_loop):
+        """Bring the layer-0 cache up to date with every graph in the arena, eagerly.  A replayed hipGraph only
+        GATHERS from the cache: whoever replays one must call this first (it may re-allocate the cache, which the
+        replayer's address check then notices)."""
+        if self.feat is not None and self.feat.buf.numel() * 4 <= self.AGG0_CACHE_BYTES:
+            self._agg0_store(average, self_loop)
+
     def features_and_agg0(self, batch, average, self_loop):
         """(X_concat, cached layer-0 aggregate) for the batch; the second is None when the cache would
         exceed AGG0_CACHE_BYTES (wide one-hot inputs on huge pools)."""
@@ -329,6 +345,7 @@ class StaticBatch:
         b.node_off = template.node_off.clone()
         b.rp_off, b.col_off = template.rp_off.clone(), template.col_off.clone()
         b.gids = template.gids.clone()
+        b.feat_base = template.feat_base.clone()
         if template.symmetric:
             b.t_rp_off, b.t_col_off = b.rp_off, b.col_off
         else:
@@ -344,6 +361,71 @@ class StaticBatch:
         b.rp_off.copy_(other.rp_off, non_blocking=True)
         b.col_off.copy_(other.col_off, non_blocking=True)
         b.gids.copy_(other.gids, non_blocking=True)
+        b.feat_base.copy_(other.feat_base, non_blocking=True)
         if not b.symmetric:
             b.t_rp_off.copy_(other.t_rp_off, non_blocking=True)
             b.t_col_off.copy_(other.t_col_off, non_blocking=True)
+
+
+class PackedStaticBatch:
+    """A fixed-shape Batch (B graphs of n nodes each) whose descriptors live in ONE device buffer that is refilled
+    from the host with ONE pinned copy: load_gids(arena ids).  What the replayed evaluation forward reads
+    (gnm/graphs.py CapturedEval): assembling a Batch the general way costs ~15 tiny device ops (~150 us of host
+    time), which is most of a B = 1 forward."""
+
+    def __init__(self, arena, B, n, symmetric, nnz_max):
+        dev = arena.device
+        self.arena, self.B, self.n = arena, int(B), int(n)
+        words = 6 * B + (B + 2) // 2                       # 6 int64 vectors + node_off as int32 pairs
+        node_off = np.arange(B + 1, dtype=np.int64) * n
+        # a small ring of pinned staging buffers: the copy is asynchronous, so a buffer may only be rewritten once
+        # the copy that read it has run (an event per slot; by the time a slot comes round again it has)
+        self._ring, self._events, self._next = [], [], 0
+        for _ in range(32 if dev.type == "cuda" else 1):
+            h = torch.zeros(words, dtype=torch.int64)
+            if dev.type == "cuda":
+                h = h.pin_memory()
+            h.numpy()[6 * B:].view(np.int32)[:B + 1] = node_off       # constant: equal-size graphs
+            self._ring.append(h)
+            self._events.append(None)
+        self._dev = torch.zeros(words, dtype=torch.int64, device=dev)
+        dv = self._dev
+        b = Batch()
+        b.arena, b.B, b.N, b.n_max, b.n_min, b.nnz_max = arena, int(B), int(B * n), int(n), int(n), int(nnz_max)
+        b.symmetric = bool(symmetric)
+        b.rp_off, b.col_off = dv[0:B], dv[B:2 * B]
+        b.t_rp_off, b.t_col_off = (b.rp_off, b.col_off) if symmetric else (dv[2 * B:3 * B], dv[3 * B:4 * B])
+        b.gids = dv[4 * B:5 * B]
+        b.feat_base = dv[5 * B:6 * B]
+        b.node_off = dv[6 * B:].view(torch.int32)[:B + 1]
+        b.node_off_host = node_off
+        self.batch = b
+        self._dev.copy_(self._ring[0])
+
+    def fits(self, gh):
+        """can the graphs with arena ids gh (host int64 array) be loaded? (same count, node count, symmetry class;
+        no more edges than the launch parameters were sized for)"""
+        tb = self.arena._tables()
+        b = self.batch
+        return (gh.shape[0] == b.B and bool((tb["n_host"][gh] == self.n).all())
+                and bool(tb["sym_host"][gh].all()) == b.symmetric and int(tb["nnz_host"][gh].max()) <= b.nnz_max)
+
+    def load_gids(self, gh):
+        tb = self.arena._tables()
+        i = self._next
+        self._next = (i + 1) % len(self._ring)
+        if self._events[i] is not None:
+            self._events[i].synchronize()
+        B = self.B
+        hv = self._ring[i].numpy()
+        np.take(tb["rp_host"], gh, out=hv[0:B])
+        np.take(tb["col_host"], gh, out=hv[B:2 * B])
+        np.take(tb["trp_host"], gh, out=hv[2 * B:3 * B])
+        np.take(tb["tcol_host"], gh, out=hv[3 * B:4 * B])
+        hv[4 * B:5 * B] = gh
+        np.take(tb["feat_host"], gh, out=hv[5 * B:6 * B])
+        self._dev.copy_(self._ring[i], non_blocking=True)
+        if self._dev.is_cuda:
+            if self._events[i] is None:
+                self._events[i] = torch.cuda.Event()
+            self._events[i].record(torch.cuda.current_stream(self._dev.device))

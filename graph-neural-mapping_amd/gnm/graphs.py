@@ -13,7 +13,7 @@ Everything shape-like is frozen at capture: B, N (equal-size graphs), model opti
 import numpy as np
 import torch
 
-from .arena import StaticBatch
+from .arena import PackedStaticBatch, StaticBatch
 
 
 class CapturedTrainStep:
@@ -78,6 +78,9 @@ class CapturedTrainStep:
         np.random.permutation(B) of graphcnn.py:199 (drawn here if None)."""
         if perm is None:
             perm = np.random.permutation(batch.B)
+        if self._agg0_cache:        # graphs added since the capture: their layer-0 aggregate must exist before a replay
+            sp = self.model._spec
+            batch.arena.refresh_agg0(sp.n_avg, not sp.learn_eps)
         if self._arena_buffers() != self._arena_ptrs:
             raise RuntimeError("the graph arena was re-allocated after this step was captured (graphs were added): "
                                "add every graph before building CapturedTrainStep / FusedTrainStep, or build a new one")
@@ -86,3 +89,70 @@ class CapturedTrainStep:
         self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
         self.graph.replay()
         return self.loss
+
+
+class CapturedEval:
+    """GIN_InfoMaxReg.forward of B equal-size graphs in eval mode as ONE replayed hipGraph.
+
+    The reference evaluates one graph per forward over the whole training set every epoch (main.py:49-57, 154;
+    also get_latent_space, main.py:71-82).  Eager, such a forward is ~110 launches = ~1.4 ms of Python for ~0.15 ms
+    of GPU work; replayed it is one pinned descriptor copy + one graph launch.  The kernels, their launch
+    parameters and their order are the eager path's, so results are bitwise identical (tests/test_gpu_eval_replay.py).
+    Outputs live in static buffers that the next run() overwrites: callers clone what they keep."""
+
+    def __init__(self, model, gids_host, warmup=2):
+        arena = model.arena()
+        tb = arena._tables()
+        gh = np.asarray(gids_host, dtype=np.int64)
+        n = int(tb["n_host"][gh[0]])
+        if not (tb["n_host"][gh] == n).all():
+            raise ValueError("CapturedEval needs equal-size graphs (as the discriminator does, discriminator.py:24)")
+        nnz = int(tb["nnz_host"][gh].max())
+        nnz_cap = max(4096, 1 << (nnz - 1).bit_length()) if nnz > 0 else 4096     # launch parameters sized for this
+        self.model = model
+        self.static = PackedStaticBatch(arena, gh.shape[0], n, bool(tb["sym_host"][gh].all()), nnz_cap)
+        self.static.load_gids(gh)
+        dev = arena.device
+        B = gh.shape[0]
+        self.perm = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._params = [p for p in model.parameters()] + [b for b in model.buffers()]
+        self._param_ptrs = tuple(t.data_ptr() for t in self._params)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._forward()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.c_logit, self.d_logit, self.g_f = self._forward()
+        torch.cuda.synchronize(dev)
+        self._arena_ptrs = self._arena_buffers()
+
+    def _arena_buffers(self):
+        a = self.static.arena
+        return (a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), a.feat.buf.data_ptr(),
+                tuple(sorted((k, v["buf"].data_ptr()) for k, v in a._agg0.items() if v["buf"] is not None)))
+
+    def _forward(self):
+        m = self.model
+        bt = self.static.batch
+        with torch.no_grad():
+            X, P0 = bt.arena.features_and_agg0(bt, m._spec.n_avg, not m._spec.learn_eps)
+            return m._run(bt, X, self.perm, want_disc=True, P0=P0)
+
+    def valid_for(self, gh):
+        """still replayable for these graphs?  (shape fits, and neither the arena nor the parameters moved)"""
+        return (self.static.fits(gh) and self._arena_buffers() == self._arena_ptrs
+                and tuple(t.data_ptr() for t in self._params) == self._param_ptrs)
+
+    def run(self, gh, perm):
+        """replay on the graphs with arena ids gh (host int64 [B]) and the permutation of graphcnn.py:199;
+        returns the static (c_logit, d_logit, g_f)"""
+        self.static.load_gids(gh)
+        if self.static.B > 1:      # (B = 1: the permutation of one graph is [0], as captured)
+            # a fresh pinned tensor per call: torch's pinned-memory allocator keeps it alive until the copy has run
+            self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
+        self.graph.replay()
+        return self.c_logit, self.d_logit, self.g_f

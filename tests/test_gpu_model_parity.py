@@ -80,6 +80,7 @@ def capture_layers(model):
     """pooled (input of the MLP) and hidden (layer output) of every layer, from the
     tensors the autograd Function saved."""
     from gnm import core
+    model.eval_replay = False       # the hook below copies to the host inside the forward: not capturable
     store = {}
     orig = core.encoder_forward
 

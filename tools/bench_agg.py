@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--cold", action="store_true")
     ap.add_argument("--tag", default=os.environ.get("GNM_HIP_LIB", "product"))
     ap.add_argument("--check", action="store_true", help="spot-check the result against a dense fp64 product")
+    ap.add_argument("--ab", default=None,
+                    help="comma-separated extra builds of the library (paths) timed INTERLEAVED with the loaded one: "
+                         "launch i of every build before launch i + 1 of any -- clock drift and neighbours hit all alike")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     pool = synth.make_pool("dense_fc", args.pool)
@@ -62,9 +65,30 @@ def main():
     a = ar
     flush = torch.empty(1 << 28, dtype=torch.float32, device=dev) if args.cold else None
 
-    def run(mode):
+    import ctypes as C
+    from gnm import _cabi
+    libs = [(os.path.basename(str(args.tag)), core.lib)]
+    for path in (args.ab.split(",") if args.ab else []):
+        L = C.CDLL(path)
+        for name, (res, at) in _cabi.SIGNATURES.items():
+            if hasattr(L, name):
+                getattr(L, name).restype = res
+                getattr(L, name).argtypes = at
+        libs.append((os.path.basename(path), L))
+
+    def run(mode, lib=None):
+        lib = lib or core.lib
+        if mode in ("bwd", "phasea", "plain"):
+            bw = mode == "bwd"
+            core.check(lib.gnm_agg(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                   batch.col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                   batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, x.data_ptr(), F,
+                                   None if mode == "phasea" else y.data_ptr(), 0 if mode == "phasea" else F, F,
+                                   eps.data_ptr(), 0, 0, int(bw), h.data_ptr() if bw else None, F if bw else 0,
+                                   part.data_ptr() if bw else None, st), "gnm_agg")
+            return
         if mode == "fused":
-            core.check(core.lib.gnm_agg_fwd_bnrelu(
+            core.check(lib.gnm_agg_fwd_bnrelu(
                 a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
                 batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, x.data_ptr(), F, sc.data_ptr(),
                 sh.data_ptr(), h.data_ptr(), F, gf.data_ptr(), F, 0, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, st),
@@ -72,7 +96,7 @@ def main():
         elif mode == "bwd":
             core._agg(batch, x, y, F, eps.data_ptr(), spec, True, hfwd=h, deps_partial=part)
         elif mode == "bwdstats":
-            core.check(core.lib.gnm_agg_bwd_stats(
+            core.check(lib.gnm_agg_bwd_stats(
                 a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(), batch.t_col_off.data_ptr(),
                 a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max,
                 batch.nnz_max, x.data_ptr(), F, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, None, 0, part.data_ptr(),
@@ -86,23 +110,31 @@ def main():
 
     byt = (4 * 400 * F * 2 + 4 * E + 4 * 401) * args.batch
     for mode in args.modes.split(","):
-        for _ in range(5):
-            run(mode)
+        for _, L in libs:
+            for _ in range(5):
+                run(mode, L)
         torch.cuda.synchronize()
-        evs = []
+        evs = {name: [] for name, _ in libs}
         for _ in range(args.iters):
-            if flush is not None:
-                flush.add_(1.0)
-            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ea.record(); run(mode); eb.record()
-            evs.append((ea, eb))
+            for name, L in libs:
+                if flush is not None:
+                    flush.add_(1.0)
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(); run(mode, L); eb.record()
+                evs[name].append((ea, eb))
         torch.cuda.synchronize()
-        ms = np.array([ea.elapsed_time(eb) for ea, eb in evs])
-        med = float(np.median(ms))
-        print("AGG %-28s %-8s F=%d B=%d%s: median %.1f us (min %.1f)  %.0f GB/s canonical = %.3f of 8 TB/s  "
-              "%.2f M graph-layers/s" % (os.path.basename(str(args.tag)), mode, F, args.batch,
-                                         " cold" if args.cold else "", med * 1e3, ms.min() * 1e3, byt / med / 1e6,
-                                         byt / med / 1e6 / 8000, args.batch / med / 1e3), flush=True)
+        base = None
+        for name, _ in libs:
+            ms = np.array([ea.elapsed_time(eb) for ea, eb in evs[name]])
+            med = float(np.median(ms))
+            rel = "" if base is None else "   paired vs %s: %+.1f us (median of differences)" % (
+                libs[0][0], 1e3 * float(np.median(ms - base)))
+            if base is None:
+                base = ms
+            print("AGG %-28s %-8s F=%d B=%d%s: median %.1f us (min %.1f)  %.0f GB/s canonical = %.3f of 8 TB/s  "
+                  "%.2f M graph-layers/s%s" % (name, mode, F, args.batch, " cold" if args.cold else "", med * 1e3,
+                                              ms.min() * 1e3, byt / med / 1e6, byt / med / 1e6 / 8000,
+                                              args.batch / med / 1e3, rel), flush=True)
     if args.check:
         b1 = ar.batch_from_gids(gids[:2])
         x1 = torch.randn(b1.N, F, device=dev)
