@@ -141,6 +141,14 @@ template <int LPR>
 __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     constexpr int FS = LPR * 4;        // floats per LDS row
     constexpr int SLOTS = 64 / LPR;    // neighbour rows read per wave-instruction
+#ifdef GNM_AGG16_TUNING       // in-kernel timeline (tools/agg_timeline.py)
+#define GNM_GSTAMP(k)                                                                                         \
+    if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
+        p.stamps[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define GNM_GSTAMP(k)
+#endif
+    GNM_GSTAMP(0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* tile = reinterpret_cast<float4*>(smem);
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -161,7 +169,43 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
 
     // ---- phase A: HBM -> LDS, coalesced; optional 1/deg pre-scale and d-eps dot ----
     double dot = 0.0;
-    for (int i = tid; i < n * LPR; i += nthreads) {
+    int i0 = tid;
+    // full-width, 16-byte addressable slices: 8 x 16 B per thread in flight (the loop below issues ONE load per trip,
+    // inside a lane-dependent branch, i.e. one memory round trip per 16 KB of the tile: 16-32 us of a 128 KB tile)
+    if (vec_in && col0 + FS <= p.F && (!p.deps_partial || vec_h)) {       // wave-uniform
+        constexpr int UA = 8;
+        const int total = n * LPR;
+        for (; i0 + (UA - 1) * nthreads < total; i0 += UA * nthreads) {
+            float4 v[UA];
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int i = i0 + u * nthreads;
+                const int r = i / LPR, c = i - r * LPR;
+                v[u] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + r) * p.ldx + col0 + 4 * c);
+            }
+            if (p.deps_partial) {
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    const int i = i0 + u * nthreads;
+                    const int r = i / LPR, c = i - r * LPR;
+                    const float4 h = *reinterpret_cast<const float4*>(p.hfwd + (size_t)(row0 + r) * p.ldh + col0 + 4 * c);
+                    dot += (double)v[u].x * h.x + (double)v[u].y * h.y + (double)v[u].z * h.z + (double)v[u].w * h.w;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const int i = i0 + u * nthreads;
+                float4 w = v[u];
+                if (prescale) {
+                    const int r = i / LPR;
+                    const float d = (float)(drp[r + 1] - drp[r] + p.self_loop);
+                    w.x /= d; w.y /= d; w.z /= d; w.w /= d;
+                }
+                tile[i] = w;
+            }
+        }
+    }
+    for (int i = i0; i < n * LPR; i += nthreads) {
         const int r = i / LPR;
         const int c = i - r * LPR;
         const int cc = col0 + 4 * c;
@@ -200,7 +244,10 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     const bool stage_rp = !(LPR <= 4 && p.ids_in_lds);
     if (stage_rp)
         for (int i = tid; i <= n; i += nthreads) rp_s[i] = rp[i];
+    GNM_GSTAMP(1)
+    GNM_GSTAMP(2)
     __syncthreads();
+    GNM_GSTAMP(3)
 
     // ---- phase B, narrow features (FS <= 16 floats): one THREAD per (row, 16-B chunk) ------
     // The rows are so short that the wave-cooperative scheme below spends its time in
@@ -374,8 +421,9 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                     tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
                 }
                 float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
-                if (vec_out && cc + 3 < p.F) {
-                    *reinterpret_cast<float4*>(dst) = tot;
+                if (vec_out && col0 + FS <= p.F) {          // wave-uniform: ONE 16-byte store per lane (see agg16)
+                    const f32x4 t4 = {tot.x, tot.y, tot.z, tot.w};
+                    __builtin_nontemporal_store(t4, reinterpret_cast<f32x4*>(dst));
                 } else {
                     if (cc + 0 < p.F) dst[0] = tot.x;
                     if (cc + 1 < p.F) dst[1] = tot.y;
@@ -660,8 +708,23 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     } else if ((t) >= 1) {                    \
         GNM_D1(B)                             \
     }
-// nd in 0..16 double steps, exactly
-#define GNM_DLADDER(nd)                                   \
+// 8 double steps = 16 reads in flight (64 registers: the forward kernel only)
+#define GNM_D8W(S)                                                                                  \
+    {                                                                                               \
+        const f32x4 a0_ = GNM_LO(S), b0_ = GNM_HI(S), a1_ = GNM_LO(S + 1), b1_ = GNM_HI(S + 1),     \
+                    a2_ = GNM_LO(S + 2), b2_ = GNM_HI(S + 2), a3_ = GNM_LO(S + 3), b3_ = GNM_HI(S + 3), \
+                    a4_ = GNM_LO(S + 4), b4_ = GNM_HI(S + 4), a5_ = GNM_LO(S + 5), b5_ = GNM_HI(S + 5), \
+                    a6_ = GNM_LO(S + 6), b6_ = GNM_HI(S + 6), a7_ = GNM_LO(S + 7), b7_ = GNM_HI(S + 7); \
+        acc4(acc, ((a0_ + b0_) + (a1_ + b1_)) + ((a2_ + b2_) + (a3_ + b3_)));                       \
+        acc4(acc, ((a4_ + b4_) + (a5_ + b5_)) + ((a6_ + b6_) + (a7_ + b7_)));                       \
+    }
+#ifndef GNM_LADDER_MODE
+#define GNM_LADDER_MODE 0
+#endif
+// nd in 0..16 double steps.  Mode 0: exactly nd, in blocks of 4 + a tail of 2 / 1.  Tuning variants: 1 = first 8 as
+// one 16-deep block; 2 = nd rounded up to whole blocks of 4 (padding reads the zero row: no tail pieces);
+// 3 = both.
+#define GNM_DLADDER_EXACT(nd)                             \
     if ((nd) >= 4) {                                      \
         GNM_D4(0)                                         \
         if ((nd) >= 8) {                                  \
@@ -682,6 +745,55 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     } else {                                              \
         GNM_DTAIL(0, nd)                                  \
     }
+#define GNM_DLADDER_D8(nd)                                \
+    if (!STATS && (nd) >= 8) {                            \
+        GNM_D8W(0)                                        \
+        if ((nd) >= 12) {                                 \
+            GNM_D4(8)                                     \
+            if ((nd) >= 16) {                             \
+                GNM_D4(12)                                \
+            } else {                                      \
+                GNM_DTAIL(12, (nd) - 12)                  \
+            }                                             \
+        } else {                                          \
+            GNM_DTAIL(8, (nd) - 8)                        \
+        }                                                 \
+    } else {                                              \
+        GNM_DLADDER_EXACT(nd)                             \
+    }
+#define GNM_DLADDER_PAD(nd)                               \
+    if ((nd) > 0) {                                       \
+        GNM_D4(0)                                         \
+        if ((nd) > 4) {                                   \
+            GNM_D4(4)                                     \
+            if ((nd) > 8) {                               \
+                GNM_D4(8)                                 \
+                if ((nd) > 12) GNM_D4(12)                 \
+            }                                             \
+        }                                                 \
+    }
+#define GNM_DLADDER_D8PAD(nd)                             \
+    if (!STATS && (nd) > 4) {                             \
+        GNM_D8W(0)                                        \
+        if ((nd) > 8) {                                   \
+            if ((nd) > 12) {                              \
+                GNM_D8W(8)                                \
+            } else {                                      \
+                GNM_D4(8)                                 \
+            }                                             \
+        }                                                 \
+    } else {                                              \
+        GNM_DLADDER_PAD(nd)                               \
+    }
+#if GNM_LADDER_MODE == 1
+#define GNM_DLADDER(nd) GNM_DLADDER_D8(nd)
+#elif GNM_LADDER_MODE == 2
+#define GNM_DLADDER(nd) GNM_DLADDER_PAD(nd)
+#elif GNM_LADDER_MODE == 3
+#define GNM_DLADDER(nd) GNM_DLADDER_D8PAD(nd)
+#else
+#define GNM_DLADDER(nd) GNM_DLADDER_EXACT(nd)
+#endif
 // single-register forms (ids fetched in place beyond the 128-id window: degree > 128)
 #define GNM_S1(S) acc4(acc, GNM_RD(S));
 #define GNM_S2(S)                                                \
@@ -1304,6 +1416,11 @@ static int launch_agg16(const AggArgs& a0, int B, int n_max, hipStream_t stream)
 template <int LPR>
 static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
     AggArgs a = a0;
+#ifdef GNM_AGG16_TUNING
+    a.stamps = g_agg16_stamps;
+#else
+    a.stamps = nullptr;
+#endif
     size_t lds = (size_t)(n_max + 1) * LPR * 16;
     const int max_nnz = a.ids_in_lds;             // on entry: largest nnz of the batch (0 = unknown)
     a.ids_in_lds = 0;

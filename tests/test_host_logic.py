@@ -212,3 +212,4 @@ def test_add_many_equals_add_and_symmetry_check():
         rp = np.empty(n + 1, np.int32); col = np.empty(max(E, 1), np.uint16)
         assert lib.gnm_csr_from_edge_mat(np.ascontiguousarray(em).ctypes.data, E, n, rp.ctypes.data, col.ctypes.data) == 0
         assert bool(lib.gnm_csr_is_symmetric(rp.ctypes.data, col.ctypes.data, n)) == bool((A == A.T).all()), A
+

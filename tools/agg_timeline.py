@@ -23,16 +23,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="plain")
     ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c4: 1000-node kNN graphs, F = 128 (4 slices of 32)")
     args = ap.parse_args()
     lib = core.lib
     lib.gnm_debug_set_stamps.argtypes = [C.c_void_p]
     lib.gnm_debug_set_stamps.restype = None
     dev = torch.device("cuda:0")
-    pool = synth.make_pool("dense_fc", args.batch)
+    c4 = args.config == "c4"
+    if c4:
+        args.batch = min(args.batch, 256)
+    pool = synth.make_pool("knn", args.batch) if c4 else synth.make_pool("dense_fc", args.batch)
     ar = GraphArena(dev)
     gids = np.array(ar.add_many(pool), dtype=np.int64)
     batch = ar.batch_from_gids(gids)
-    N, F, B = batch.N, 64, batch.B
+    N, F, B = batch.N, (128 if c4 else 64), batch.B
+    WG = B * (4 if c4 else 1)                 # workgroups per launch (one per graph and slice)
     x, h, y = torch.randn(N, F, device=dev), torch.randn(N, F, device=dev), torch.empty(N, F, device=dev)
     eps = torch.zeros(1, device=dev)
     spec = core.GinSpec(5, 2, True, "sum", "sum")
@@ -64,7 +69,7 @@ def main():
 
     for _ in range(5):
         run()
-    stamps = torch.zeros(B * 16 * 64, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(WG * 16 * 64, dtype=torch.int64, device=dev)
     lib.gnm_debug_set_stamps(stamps.data_ptr())
     run()
     torch.cuda.synchronize()
@@ -74,12 +79,13 @@ def main():
     torch.cuda.synchronize()
     lib.gnm_debug_set_stamps(None)
     ms = e0.elapsed_time(e1)
-    raw = stamps.cpu().numpy().reshape(B, 16, 64)
+    raw = stamps.cpu().numpy().reshape(WG, 16, 64)
+    raw = raw[:, (raw[0, :, 0] != 0), :]          # waves that exist (8 per workgroup in the sliced kernel)
     s = raw.astype(np.float64)
     # the counter is per XCD (not synchronised across the chip): only differences inside one workgroup mean anything
     wg_ticks = (s[:, :, 63].max(1) - s[:, :, 0].min(1))
     # clock: 1024 workgroups run back to back on 256 CUs, so (ticks per workgroup) x B / 256 ~ launch duration
-    ghz = wg_ticks.mean() * B / 256.0 / (ms * 1e6)          # ticks per ns (an upper bound: ignores dispatch gaps)
+    ghz = wg_ticks.mean() * WG / 256.0 / (ms * 1e6)          # ticks per ns (an upper bound: ignores dispatch gaps)
     us = lambda ticks: ticks / (ghz * 1e3)
     print("mode %s: launch %.1f us by HIP events (stamped build); workgroup %.0f ticks -> clock <= %.2f GHz" %
           (args.mode, ms * 1e3, wg_ticks.mean(), ghz))
@@ -96,7 +102,7 @@ def main():
     tail = us((s[:, :, 63].max(1, keepdims=True) - s[:, :, 63]).mean())
     first_group = us((s[:, :, 5] - s[:, :, 4]).mean())
     last_group = us((s[:, :, 5 + 5 * (ng - 1)] - s[:, :, 4 + 5 * (ng - 1)]).mean())
-    print("per graph (mean over %d workgroups x 16 waves), %d groups per wave:" % (B, ng))
+    print("per workgroup (mean over %d workgroups x %d waves), %d groups per wave:" % (WG, raw.shape[1], ng))
     print("  own phase A (tile load)         %6.2f us" % phaseA)
     print("  drain vmcnt(0)                  %6.2f us" % drain)
     print("  barrier wait                    %6.2f us" % barrier)
@@ -105,7 +111,7 @@ def main():
     print("  between groups / loop exit      %6.2f us" % inter)
     print("  wave total                      %6.2f us" % wave_total)
     print("  idle after own last group       %6.2f us   (waiting for the workgroup's slowest wave)" % tail)
-    print("  workgroup total                 %6.2f us   x %d graphs / 256 CUs = %.1f us" % (wg_total, B, wg_total * B / 256))
+    print("  workgroup total                 %6.2f us   x %d workgroups / 256 CUs = %.1f us" % (wg_total, WG, wg_total * WG / 256))
     # start skew of successive workgroups on one CU cannot be seen from here; launch - sum = dispatch gaps
     rows = []
     for k in range(ng):
