@@ -21,6 +21,7 @@
 
 // tuning knobs, read once per process
 static bool lin_force_generic() { static const bool v = getenv("GNM_LIN_GENERIC") != nullptr; return v; }
+static bool lin_no_stream() { static const bool v = getenv("GNM_LIN_NO_STREAM") != nullptr; return v; }   // tuning: A/B
 static bool linbwd_no_samez() { static const bool v = getenv("GNM_LINBWD_NO_SAMEZ") != nullptr; return v; }
 
 struct LinArgs {
@@ -35,7 +36,18 @@ struct LinArgs {
     int N, K, H;
     int w_kmajor;            // 0: W[h*ldw+k] (torch Linear weight);  1: W[k*ldw+h]
     int pro_relu;
+    unsigned long long* stamps;   // tuning builds only (gnm_debug_set_lin_stamps): [block][4 waves][64] s_memtime
 };
+
+#ifdef GNM_LIN_TUNING
+static unsigned long long* g_lin_stamps = nullptr;
+extern "C" void gnm_debug_set_lin_stamps(void* p) { g_lin_stamps = reinterpret_cast<unsigned long long*>(p); }
+#define GNM_LSTAMP(k)                                                                                         \
+    if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
+        p.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define GNM_LSTAMP(k)
+#endif
 
 template <int KC, int HT>
 __global__ void __launch_bounds__(256) gnm_lin_kernel(const LinArgs p) {
@@ -221,6 +233,7 @@ __global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
     const int i = lane & 31;
     const int h = lane >> 5;
     float* Xs = Xs_all + wave * 32 * XS;
+    GNM_LSTAMP(0)
 
     if (p.w_kmajor) {
         for (int idx = tid; idx < p.K * HP; idx += 256) {
@@ -234,6 +247,8 @@ __global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
         }
     }
     __syncthreads();
+    GNM_LSTAMP(1)
+    int tk = 0;
 
     const int ntiles = (p.N + 31) / 32;
     double st1[HT], st2[HT];
@@ -260,6 +275,7 @@ __global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
     }
     for (; t < ntiles; t += tstride) {
         const int r0 = t * 32;
+        GNM_LSTAMP(2 + 4 * min(tk, 14))
         f32x16 acc[HT];
 #pragma unroll
         for (int c = 0; c < HT; ++c)
@@ -306,6 +322,7 @@ __global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
                     }
                 }
             }
+            GNM_LSTAMP(3 + 4 * min(tk, 14))
             const float* wrow = Wt + (size_t)(kb + KH * h) * HP + i;
 #pragma unroll
             for (int s = 0; s < KH; ++s) {
@@ -318,6 +335,7 @@ __global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        GNM_LSTAMP(4 + 4 * min(tk, 14))
 
         // epilogue: bias, statistics (valid rows only), transpose through LDS, 16-B stores
 #pragma unroll
@@ -348,7 +366,10 @@ __global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        GNM_LSTAMP(5 + 4 * min(tk, 14))
+        ++tk;
     }
+    GNM_LSTAMP(62)
 
     if (p.stats_partial) {
         __syncthreads();
@@ -382,6 +403,235 @@ static int launch_lin_fast(const LinArgs& a, int grid, hipStream_t s) {
     if (lds > (size_t)kLdsBudget) return GNM_ERR_UNSUPPORTED;
     GNM_ALLOW_FULL_LDS((&gnm_lin_fast_kernel<KC, HT>));
     hipLaunchKernelGGL((gnm_lin_fast_kernel<KC, HT>), dim3(grid), dim3(256), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Streaming variant for K == KC (the whole input row is one chunk: every hidden Linear of the model).  Same tile
+// arithmetic as the pipelined kernel above; what changes is how a wave's memory operations are ordered and counted.
+// gfx950 retires vector-memory operations IN ORDER, stores included, and `s_waitcnt vmcnt(n)` waits until at most n are
+// outstanding.  The pipelined kernel issues  loads(t+1) .. stores(t)  and then needs loads(t+1): the compiler could
+// not prove that the stores behind them had been issued on every path (row guards, the first trip through the loop),
+// so it waited for vmcnt(7..0) -- i.e. for the STORES of the previous tile to land in HBM -- before staging the next
+// tile, and for vmcnt(0) (bias load, never counted down) in front of every epilogue.  The in-kernel timeline showed
+// those two waits as ~22 % + part of the epilogue's 25 % of a tile's time.  Here
+//   * loads and stores are buffer instructions whose descriptor covers exactly the tile's valid rows: rows past N
+//     (and whole tiles past the last) are dropped by the address check, so every access is issued unconditionally;
+//   * the first tile is peeled, so the loop is entered with the same  loads, stores  queue its back edge carries;
+//   * bias / prologue constants are waited for once, before the first tile.
+// The wait in front of the staging writes becomes vmcnt(15..8): the previous tile's stores drain under this tile's
+// MFMAs instead of in front of them.
+// ---------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gnm_tile_rsrc(const float* base, long long rows, int ld, int width) {
+    // raw buffer (stride 0): byte offsets >= num_records read 0 / are not written
+    const unsigned bytes = rows > 0 ? (unsigned)(((rows - 1) * ld + width) * 4) : 0u;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+
+template <int KC, int HT>
+__global__ void __launch_bounds__(256) gnm_lin_stream_kernel(const LinArgs p) {
+    constexpr int HP = HT * 32;
+    constexpr int XS = (KC > HP ? KC : HP) + 4;
+    constexpr int C4 = KC / 4;
+    constexpr int KH = KC / 2;
+    constexpr int NLD = (32 * C4) / 64;           // 16-B loads per lane per tile
+    constexpr int RSTEP = 64 / C4;                // rows between a lane's consecutive loads
+    constexpr int O4 = HP / 4;
+    constexpr int NST = (32 * O4) / 64;           // 16-B stores per lane per tile
+    constexpr int WSTEP = 64 / O4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Wt = reinterpret_cast<float*>(smem);                   // [KC][HP]
+    float* Xs_all = Wt + (size_t)KC * HP;                         // [4][32][XS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    float* Xs = Xs_all + wave * 32 * XS;
+    GNM_LSTAMP(0)
+
+    const int c4 = lane % C4;
+    const int lrow0 = lane / C4;
+    float bias_r[HT];
+#pragma unroll
+    for (int c = 0; c < HT; ++c) bias_r[c] = p.bias ? p.bias[32 * c + i] : 0.f;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool pro = p.pro_scale != nullptr;
+    if (pro) {
+        sc = *reinterpret_cast<const float4*>(p.pro_scale + 4 * c4);
+        sh = *reinterpret_cast<const float4*>(p.pro_shift + 4 * c4);
+    }
+    const int ntiles = (p.N + 31) / 32;
+    const int tstride = gridDim.x * 4;
+    const int in_voff = (lrow0 * p.ldx + 4 * c4) * 4;            // byte offsets inside a tile's descriptor
+    const int in_step = RSTEP * p.ldx * 4;
+    const int out_voff = ((lane / O4) * p.ldz + 4 * (lane % O4)) * 4;
+    const int out_step = WSTEP * p.ldz * 4;
+
+    u32x4 raw[NLD];
+    auto load_tile = [&](int tile) {
+        const long long row0 = (long long)tile * 32;
+        const __amdgpu_buffer_rsrc_t rs = gnm_tile_rsrc(p.X + row0 * p.ldx, min((long long)p.N - row0, 32LL), p.ldx, KC);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, j * in_step, 0);
+    };
+    int t = blockIdx.x * 4 + wave;
+    load_tile(t);                                 // the first tile arrives while the weight is staged
+
+    // weight -> LDS as Wt[k][h].  torch layout W[h][k]: a lane takes 4 consecutive k of one h (16-B global read) and
+    // consecutive lanes take consecutive h, so the four transposed LDS writes of a wave fall in consecutive banks.
+    if (p.w_kmajor) {
+#pragma unroll
+        for (int it = 0; it < (KC * O4) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int k = idx / O4, h4 = idx - k * O4;
+            *reinterpret_cast<float4*>(Wt + k * HP + 4 * h4) = *reinterpret_cast<const float4*>(p.W + (size_t)k * p.ldw + 4 * h4);
+        }
+    } else {
+        float4 w[(C4 * HP) / 256];
+#pragma unroll
+        for (int it = 0; it < (C4 * HP) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int k4 = idx / HP, hh = idx - k4 * HP;
+            w[it] = *reinterpret_cast<const float4*>(p.W + (size_t)hh * p.ldw + 4 * k4);
+        }
+#pragma unroll
+        for (int it = 0; it < (C4 * HP) / 256; ++it) {
+            const int idx = tid + 256 * it;
+            const int k4 = idx / HP, hh = idx - k4 * HP;
+            Wt[(4 * k4 + 0) * HP + hh] = w[it].x;
+            Wt[(4 * k4 + 1) * HP + hh] = w[it].y;
+            Wt[(4 * k4 + 2) * HP + hh] = w[it].z;
+            Wt[(4 * k4 + 3) * HP + hh] = w[it].w;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): nothing from the preamble is pending inside the tile loop
+    __syncthreads();
+    GNM_LSTAMP(1)
+    int tk = 0;
+
+    double st1[HT], st2[HT];
+#pragma unroll
+    for (int c = 0; c < HT; ++c) { st1[c] = 0.0; st2[c] = 0.0; }
+    auto do_tile = [&](int t) {
+        const int r0 = t * 32;
+        GNM_LSTAMP(2 + 4 * min(tk, 14))
+        f32x16 acc[HT];
+#pragma unroll
+        for (int c = 0; c < HT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            float4 v = __builtin_bit_cast(float4, raw[j]);
+            if (pro) {
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (p.pro_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            *reinterpret_cast<float4*>(Xs + (lrow0 + j * RSTEP) * XS + 4 * c4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float a[KH];
+#pragma unroll
+        for (int j = 0; j < KH / 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 4 * j);
+            a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+        }
+        load_tile(t + tstride);                   // past the last tile: an empty descriptor, no memory traffic
+        GNM_LSTAMP(3 + 4 * min(tk, 14))
+        const float* wrow = Wt + (size_t)(KH * h) * HP + i;
+#pragma unroll
+        for (int s = 0; s < KH; ++s) {
+#pragma unroll
+            for (int c = 0; c < HT; ++c) {
+                const float bv = wrow[s * HP + 32 * c];
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bv, acc[c], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // A fragments are in registers before the staging image is reused
+        GNM_LSTAMP(4 + 4 * min(tk, 14))
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float z = acc[c][r] + bias_r[c];
+                Xs[lrow * XS + 32 * c + i] = z;
+                if (r0 + lrow < p.N) {
+                    s1 += z;
+                    s2 += z * z;
+                }
+            }
+            st1[c] += (double)s1;
+            st2[c] += (double)s2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, min(p.N - r0, 32), p.ldz, HP);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int idx = lane + 64 * st;
+            const int row = idx / O4, oc = idx - row * O4;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(Xs + row * XS + 4 * oc);
+            // row step in the VECTOR offset, scalar offset 0: with an SGPR soffset hipcc (ROCm 7.2) schedules a VALU
+            // write of the data registers straight behind a 16-byte buffer store (its hazard table exempts that form)
+            // and on gfx950 the store then picks up the new value in some lanes -- seen as address integers in Z.
+            __builtin_amdgcn_raw_buffer_store_b128(v, rz, out_voff + st * out_step, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        GNM_LSTAMP(5 + 4 * min(tk, 14))
+        ++tk;
+    };
+
+    if (t < ntiles) {
+        do_tile(t);                               // peeled: the loop below starts with loads(t+1), stores(t) in flight
+        for (t += tstride; t < ntiles; t += tstride) do_tile(t);
+    }
+    GNM_LSTAMP(62)
+
+    if (p.stats_partial) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);   // [4 waves][2][HP]
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            const double a1 = st1[c] + __shfl_xor(st1[c], 32, 64);
+            const double a2 = st2[c] + __shfl_xor(st2[c], 32, 64);
+            if (h == 0) {
+                red[(wave * 2 + 0) * HP + 32 * c + i] = a1;
+                red[(wave * 2 + 1) * HP + 32 * c + i] = a2;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * HP; idx += 256) {
+            const int which = idx / HP, col = idx - which * HP;
+            double s = 0.0;
+            for (int w = 0; w < 4; ++w) s += red[(w * 2 + which) * HP + col];
+            p.stats_partial[((size_t)blockIdx.x * 2 + which) * p.H + col] = s;
+        }
+    }
+}
+
+template <int KC, int HT>
+static int launch_lin_stream(const LinArgs& a, int grid, hipStream_t s) {
+    constexpr int HP = HT * 32;
+    constexpr int XS = (KC > HP ? KC : HP) + 4;
+    size_t lds = (size_t)KC * HP * 4 + (size_t)4 * 32 * XS * 4;
+    const size_t red = (size_t)4 * 2 * HP * 8;
+    if (red > lds) lds = red;
+    if (lds > (size_t)kLdsBudget) return GNM_ERR_UNSUPPORTED;
+    GNM_ALLOW_FULL_LDS((&gnm_lin_stream_kernel<KC, HT>));
+    hipLaunchKernelGGL((gnm_lin_stream_kernel<KC, HT>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
@@ -433,6 +683,11 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
     a.X = X; a.W = W; a.bias = bias; a.Z = Z; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
     a.stats_partial = stats_partial; a.ldx = ldx; a.ldw = ldw; a.ldz = ldz; a.N = N; a.K = K; a.H = H;
     a.w_kmajor = w_kmajor; a.pro_relu = pro_relu;
+#ifdef GNM_LIN_TUNING
+    a.stamps = g_lin_stamps;
+#else
+    a.stamps = nullptr;
+#endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = gnm_linear_grid(N);
     const int HT = (H + 31) / 32;
@@ -444,6 +699,16 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
     if (aligned && (H % 32) == 0 && (K % 32) == 0 && !lin_force_generic()) {
         const int kcf = (K % 64) == 0 ? 64 : 32;
         int rc = GNM_ERR_UNSUPPORTED;
+        // one chunk per row and descriptors that fit 32-bit offsets: the streaming kernel
+        const bool small_ld = (long long)ldx * 32 * 4 < (1LL << 31) && (long long)ldz * 32 * 4 < (1LL << 31);
+        const bool w_vec = (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+        if ((K == 32 || K == 64) && small_ld && w_vec && !lin_no_stream()) {
+#define GNM_LINS_CASE(KC_, HT_) if (K == KC_ && HT == HT_) rc = launch_lin_stream<KC_, HT_>(a, grid, s);
+            GNM_LINS_CASE(32, 1) GNM_LINS_CASE(32, 2) GNM_LINS_CASE(32, 3) GNM_LINS_CASE(32, 4)
+            GNM_LINS_CASE(64, 1) GNM_LINS_CASE(64, 2) GNM_LINS_CASE(64, 3) GNM_LINS_CASE(64, 4)
+#undef GNM_LINS_CASE
+            if (rc != GNM_ERR_UNSUPPORTED) return rc;
+        }
 #define GNM_LINF_CASE(KC_, HT_) if (kcf == KC_ && HT == HT_) rc = launch_lin_fast<KC_, HT_>(a, grid, s);
         GNM_LINF_CASE(32, 1) GNM_LINF_CASE(32, 2) GNM_LINF_CASE(32, 3) GNM_LINF_CASE(32, 4)
         GNM_LINF_CASE(64, 1) GNM_LINF_CASE(64, 2) GNM_LINF_CASE(64, 3) GNM_LINF_CASE(64, 4)
