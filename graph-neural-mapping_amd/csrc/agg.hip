@@ -33,39 +33,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-struct AggArgs {
-    const int32_t* rowptr;     // gather structure arena (forward CSR, or transposed for backward)
-    const uint16_t* col;       // graph-local column ids
-    const int64_t* b_rp_off;   // [B] offset of graph b's rowptr block
-    const int64_t* b_col_off;  // [B] offset of graph b's col block
-    const int32_t* deg_rowptr; // forward CSR rowptr arena (degrees for the backward pre-scale)
-    const int64_t* b_deg_off;  // [B]
-    const int32_t* node_off;   // [B+1] first row of each graph in the batch
-    const float* x;
-    float* y;
-    const float* eps;          // device pointer to eps[layer], or null
-    const float* hfwd;         // backward: forward input of the layer (for d eps), or null
-    double* deps_partial;      // [B * nslices] or null
-    int ldx, ldy, ldh;
-    int F;                     // valid feature width
-    int nslices;
-    int average, self_loop, backward;
-    // optional fusion (agg16, backward, one slice): y is the gradient arriving at relu(bn(sZ)) of the layer
-    // below -- add the readout / discriminator terms, apply that ReLU mask, write G and reduce the
-    // BatchNorm-backward sums (replaces gnm_bn_relu_bwd_stats for that BatchNorm)
-    const float* sZ; const float* s_scale; const float* s_shift; const float* s_mean; const float* s_rstd;
-    const float* s_dpool; const float* s_dsc1; const float* s_U; const int32_t* s_inv_perm; const float* s_s2sum;
-    double* s_partial;         // [B][2][64]
-    int ldsz, ld_dpool, ld_U, s_avg, n_batch;
-    int ids_in_lds;            // narrow slices: the graph's column ids are staged in LDS (max_nnz given)
-    int debug;                 // tuning only (GNM_AGG16_DEBUG): 1 no id loads, 2 no epilogue/store, 4 no combine
-    unsigned long long* stamps;   // tuning only: per-wave s_memtime stamps, [workgroup][16 waves][64] (gnm_debug_set_stamps)
-    // forward prologue (agg16 only): the input is Z of the previous layer's last Linear; the tile load applies that
-    // layer's outer BatchNorm + ReLU, writes the activation h (p_hout) and its graph readout (p_gf) on the way
-    const float* p_scale; const float* p_shift;
-    float* p_hout; float* p_gf;
-    int p_ldh, p_ldgf, p_gf_avg;
-};
+#include "gnm_agg_args.h"
 
 template <int S>
 __device__ __forceinline__ unsigned row_bcast16(unsigned v) {
@@ -1405,6 +1373,11 @@ static int launch_agg16(const AggArgs& a0, int B, int n_max, hipStream_t stream)
     static const int env_threads = gnm_env_int("GNM_AGG16_THREADS", 0);   // tuning knob for tools/bench_agg.py
     if (env_threads >= 64 && env_threads <= 1024 && (env_threads & 63) == 0) threads = env_threads;
     if (reinterpret_cast<uintptr_t>(a.col) & 3) return GNM_ERR_UNSUPPORTED;     // column ids are fetched as aligned pairs
+    // the reductions at the end of the kernel reuse the tile's LDS: [64] d-eps slots + [waves][2][64] doubles of column
+    // statistics.  A batch of very small graphs (n_max < 17) has a tile smaller than that (found by
+    // tests/test_gpu_aggm.py, graphs of 3 nodes: the sums lost every contribution written past the allocation)
+    const size_t red = (size_t)(64 + (threads / 64) * 128) * 8;
+    if (lds < red) lds = red;
     if (a.sZ)
         hipLaunchKernelGGL(gnm_agg16_kernel<true>, dim3(B * a.nslices), dim3(threads), lds, stream, a);
     else

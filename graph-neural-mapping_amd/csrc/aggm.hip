@@ -1,0 +1,520 @@
+// GIN neighbour aggregation on the matrix cores (gfx950), for graphs dense enough that gathering pays less than
+// multiplying: same operation, same fused prologues / epilogues and same C-ABI argument meaning as agg.hip
+// (torch.spmm(Adj_block, h) + degree / (1 + eps) terms, /root/reference models/graphcnn.py:154-161, :178-182 and its
+// autograd backward), but the graph's adjacency is a BIT matrix and the neighbour sum is  A (0/1) x h  on MFMA.
+//
+// Why: the benchmark graphs (400 nodes, mean degree 119: 30 % dense) make the LDS gather of agg.hip read 119 x 256 B
+// per output row; at ~86 % of the LDS peak that is ~160 us per layer launch and cannot go lower.  As a product the
+// same sum is 13 x 2 x 25 MFMA 32x32x16 steps per graph and operand plane; the bit matrix is 21 KB per graph instead
+// of 95 KB of column ids, and HBM (features in, result out) becomes the bound.
+//
+// fp32 exactness: the matrix cores multiply bf16.  A is 0/1 (exact).  h is split into three bf16 planes by
+// truncation, h = h1 + h2 + h3 with h1 = top 16 bits of h, h2 = top 16 bits of (h - h1), h3 = h - h1 - h2 (8
+// significant bits each, every subtraction exact), so every product is exact and the only rounding is the fp32
+// accumulation inside the MFMA -- the same kind and size of error as the fp32 sum of the gather (whose order is not
+// the reference's either).  tests/test_gpu_aggm.py holds it to the CSR kernels and the fp64 oracle.
+// One difference by construction: a non-finite feature (inf / NaN) reaches every row of its graph (0 x NaN = NaN),
+// not only its neighbours as in the gather -- either way the forward is lost.
+//
+// One workgroup (512 threads, two per CU) = one graph x one 32-column block of the feature matrix:
+//   phase A  the [n, 32] tile is read from HBM once (16 B per lane), the prologue of the launch form is applied
+//            (BatchNorm + ReLU + readout, or the 1/deg pre-scale of the "average" backward), and the three planes
+//            are written to LDS transposed into the MFMA B-operand order [k / 8][column][k % 8];
+//   phase B  wave w owns output row blocks w and w + 8 (32 rows each).  Per 16-node step it expands its rows' 16
+//            adjacency bits into the bf16 A operand through a 16-entry LDS table (nibble -> four bf16), reads the three
+//            B fragments (ds_read_b128, lane-linear: conflict free) and issues 3 (6) MFMAs;
+//   epilogue on the accumulators (lane = column, 16 rows per lane): self term, degree division, the fused
+//            backward terms and BatchNorm statistics of gnm_agg_bwd_stats, 128-B row segments stored.
+// The row-block -> wave map is static, so every reduction (column statistics, d eps, readout) has a fixed order.
+#include "gnm_agg_args.h"
+#include <string.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+static constexpr int kAggmThreads = 512;
+static constexpr int kAggmMaxN = 416;            // 3 planes x 416 x 32 x 2 B + table + scratch: two workgroups per CU
+static constexpr int kAggmScratch = 128 + 1024;  // nibble table + readout partials
+
+__device__ __forceinline__ unsigned bf16_pair_hi(unsigned lo_word, unsigned hi_word) {
+    // (top 16 bits of hi_word) : (top 16 bits of lo_word)
+    return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
+}
+
+template <bool STATS>
+__global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // ---- which graph / column block: the blocks of one graph sit 8 apart, i.e. on the same XCD (one L2 serves the
+    //      bit matrix and the tile to all of them)
+    const int nc = p.F >> 5;                                     // 32-column blocks per graph
+    const int grp = blockIdx.x / (8 * nc), within = blockIdx.x - grp * (8 * nc);
+    const int b = grp * 8 + (within & 7);
+    const int cb = within >> 3;
+    if (b >= p.n_graphs) return;
+    const int row0 = p.node_off[b];
+    const int n = p.node_off[b + 1] - row0;
+    const int col0 = cb * 32;
+    const int W = (n + 31) >> 5;                                 // words per bit row = 32-row blocks
+    const int ksteps = (n + 15) >> 4;
+    const int n16 = ksteps * 16;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const unsigned plane_bytes = (unsigned)p.n16_max * 64u;       // one plane: [n16_max / 8][32][8] bf16
+    char* lut = smem + 3u * plane_bytes;
+    float4* rsum = reinterpret_cast<float4*>(lut + 128);
+    const bool prescale = p.backward && p.average;
+    const bool pro = !STATS && p.p_scale != nullptr;
+    const bool dot_a = p.deps_partial && p.hfwd;
+    const int32_t* drp = p.deg_rowptr + p.b_deg_off[b];
+
+    if (tid < 16) {          // nibble e -> bf16 (bit 0, bit 1, bit 2, bit 3) as two words
+        const unsigned one = 0x3F80u;
+        u32x2 v;
+        v.x = ((tid & 1) ? one : 0u) | ((tid & 2) ? one << 16 : 0u);
+        v.y = ((tid & 4) ? one : 0u) | ((tid & 8) ? one << 16 : 0u);
+        *reinterpret_cast<u32x2*>(lut + 8 * tid) = v;
+    }
+
+    // ---- phase A ------------------------------------------------------------------------------
+    // item = (4 consecutive rows, 4 consecutive columns): four 16-B loads, transposed in registers into 8-B pieces
+    // of the planes (4 consecutive k of one column)
+    const int c4 = tid & 7;
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pro) {
+        psc = *reinterpret_cast<const float4*>(p.p_scale + col0 + 4 * c4);
+        psh = *reinterpret_cast<const float4*>(p.p_shift + col0 + 4 * c4);
+    }
+    double dot = 0.0;
+    const int nitems = (n16 >> 2) * 8;
+    constexpr int UA = 2;                                         // 416 / 4 * 8 = 832 items <= 2 x 512
+    float4 v[UA][4];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int it = tid + u * kAggmThreads;
+        const int rq = it >> 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * rq + r;
+            v[u][r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < nitems && row < n)
+                v[u][r] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + row) * p.ldx + col0 + 4 * c4);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int it = tid + u * kAggmThreads;
+        const int rq = it >> 3;
+        if (it < nitems) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * rq + r;
+                float4 w = v[u][r];
+                if (row < n) {
+                    if (dot_a) {
+                        const float4 hh = *reinterpret_cast<const float4*>(p.hfwd + (size_t)(row0 + row) * p.ldh + col0 + 4 * c4);
+                        dot += (double)w.x * hh.x + (double)w.y * hh.y + (double)w.z * hh.z + (double)w.w * hh.w;
+                    }
+                    if (pro) {
+                        w.x = fmaxf(w.x * psc.x + psh.x, 0.f); w.y = fmaxf(w.y * psc.y + psh.y, 0.f);
+                        w.z = fmaxf(w.z * psc.z + psh.z, 0.f); w.w = fmaxf(w.w * psc.w + psh.w, 0.f);
+                        *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + row) * p.p_ldh + col0 + 4 * c4) = w;
+                        csum.x += w.x; csum.y += w.y; csum.z += w.z; csum.w += w.w;
+                    }
+                    if (prescale) {
+                        // d == 0: a row nobody gathers (no forward neighbours, no self loop).  The gather never reads
+                        // its x / 0; a product would multiply it by a zero bit (0 x inf = NaN): keep it out
+                        const float d = (float)(drp[row + 1] - drp[row] + p.self_loop);
+                        const float inv_ok = d > 0.f ? 1.f : 0.f;
+                        w.x = inv_ok != 0.f ? w.x / d : 0.f; w.y = inv_ok != 0.f ? w.y / d : 0.f;
+                        w.z = inv_ok != 0.f ? w.z / d : 0.f; w.w = inv_ok != 0.f ? w.w / d : 0.f;
+                    }
+                }
+                v[u][r] = w;
+            }
+            // three planes by truncation; element (row 4 rq + r, column 4 c4 + c) -> plane word index below
+            const unsigned base = (unsigned)((((rq >> 1) * 32 + 4 * c4) * 8 + 4 * (rq & 1)) * 2);   // bytes, column 4 c4
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                unsigned x0[4], x1[4], x2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float f = c == 0 ? v[u][r].x : (c == 1 ? v[u][r].y : (c == 2 ? v[u][r].z : v[u][r].w));
+                    const unsigned a1 = __float_as_uint(f) & 0xFFFF0000u;
+                    const float r1 = f - __uint_as_float(a1);
+                    const unsigned a2 = __float_as_uint(r1) & 0xFFFF0000u;
+                    const float r2 = r1 - __uint_as_float(a2);
+                    x0[r] = a1; x1[r] = a2; x2[r] = __float_as_uint(r2);
+                }
+                u32x2 w0, w1, w2;
+                w0.x = bf16_pair_hi(x0[0], x0[1]); w0.y = bf16_pair_hi(x0[2], x0[3]);
+                w1.x = bf16_pair_hi(x1[0], x1[1]); w1.y = bf16_pair_hi(x1[2], x1[3]);
+                w2.x = bf16_pair_hi(x2[0], x2[1]); w2.y = bf16_pair_hi(x2[2], x2[3]);
+                char* dst = smem + base + c * 16;
+                *reinterpret_cast<u32x2*>(dst) = w0;
+                *reinterpret_cast<u32x2*>(dst + plane_bytes) = w1;
+                *reinterpret_cast<u32x2*>(dst + 2u * plane_bytes) = w2;
+            }
+        }
+    }
+    if (pro && p.p_gf) {       // readout partials: lanes with the same column chunk (lane & 7), then the waves
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            csum.x += __shfl_xor(csum.x, off, 64); csum.y += __shfl_xor(csum.y, off, 64);
+            csum.z += __shfl_xor(csum.z, off, 64); csum.w += __shfl_xor(csum.w, off, 64);
+        }
+        if (lane < 8) rsum[wave * 8 + lane] = csum;
+    }
+    __syncthreads();
+    if (pro && p.p_gf && tid < 8) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int w = 0; w < kAggmThreads / 64; ++w) {
+            const float4 s = rsum[w * 8 + tid];
+            t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
+        }
+        if (p.p_gf_avg) {
+            const float inv = 1.f / (float)n;
+            t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+        }
+        *reinterpret_cast<float4*>(p.p_gf + (size_t)b * p.p_ldgf + col0 + 4 * tid) = t;
+    }
+
+    // ---- phase B ------------------------------------------------------------------------------
+    const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
+    const bool need_deg = !p.backward && p.average;
+    const int col = col0 + i;
+    const float psc_i = pro ? p.p_scale[col] : 1.f, psh_i = pro ? p.p_shift[col] : 0.f;
+    float lsc = 0.f, lsh = 0.f, lmu = 0.f, s_pb = 0.f, s_ub = 0.f;
+    float ss1 = 0.f, ss2 = 0.f;
+    if constexpr (STATS) {
+        lsc = p.s_scale[col]; lsh = p.s_shift[col]; lmu = p.s_mean[col];
+        if (p.s_dpool) {
+            s_pb = p.s_dpool[(size_t)b * p.ld_dpool + col];
+            if (p.s_avg) s_pb *= 1.0f / (float)n;
+        }
+        if (p.s_dsc1) s_ub = p.s_U[(size_t)b * p.ld_U + col];
+    }
+    const int role = (wave + cb) & 7;                           // rotate with the column block: evens out the SIMDs
+    const int rbA = role, rbB = role + 8;
+    const bool two = rbB < W;
+    const uint32_t* gbits = p.adj_bits + p.b_bits_off[b];
+    const unsigned bsel = h ? 0x07050301u : 0x06040200u;         // this half-wave's byte of every 16-bit step
+    const char* bp0 = smem + lane * 16;
+    const char* bp1 = bp0 + plane_bytes;
+    const char* bp2 = bp1 + plane_bytes;
+
+    if (p.y && rbA < W) {
+        // this lane's bit rows (row rb * 32 + i), packed to the bytes its half-wave uses: byte m of pk[j] = step 4 j + m
+        unsigned pkA[7], pkB[7];
+        {
+            unsigned wa[14], wb[14];
+            const uint32_t* ra = gbits + (size_t)(rbA * 32 + i) * W;
+            const uint32_t* rb = gbits + (size_t)((two ? rbB : rbA) * 32 + i) * W;
+#pragma unroll
+            for (int d = 0; d < 14; ++d) {
+                wa[d] = d < W ? ra[d] : 0u;
+                wb[d] = d < W ? rb[d] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                pkA[j] = __builtin_amdgcn_perm(wa[2 * j + 1], wa[2 * j], bsel);
+                pkB[j] = __builtin_amdgcn_perm(wb[2 * j + 1], wb[2 * j], bsel);
+            }
+        }
+        const int32_t* frp = p.rowptr + p.b_rp_off[b];
+        const bool shuffled = STATS && p.s_dsc1 && row0 < p.n_batch;   // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
+
+        f32x16 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+        auto afrag = [&](unsigned pk, int m) -> bf16x8 {
+            const unsigned byte3 = m == 0 ? (pk << 3) : (pk >> (8 * m - 3));
+            const unsigned lo = byte3 & 0x78u, hi = (byte3 >> 4) & 0x78u;
+            const u32x2 l2 = *reinterpret_cast<const u32x2*>(lut + lo);
+            const u32x2 h2 = *reinterpret_cast<const u32x2*>(lut + hi);
+            const u32x4 q = {l2.x, l2.y, h2.x, h2.y};
+            return __builtin_bit_cast(bf16x8, q);
+        };
+#pragma unroll
+        for (int ks = 0; ks < 26; ++ks) {
+            if (ks < ksteps) {                                    // wave-uniform
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp0 + ks * 1024));
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp1 + ks * 1024));
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp2 + ks * 1024));
+                const bf16x8 aA = afrag(pkA[ks >> 2], ks & 3);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b0, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b1, accA, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b2, accA, 0, 0, 0);
+                if (two) {
+                    const bf16x8 aB = afrag(pkB[ks >> 2], ks & 3);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b0, accB, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b1, accB, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b2, accB, 0, 0, 0);
+                }
+            }
+        }
+
+        // Epilogue on the accumulators (lane = column, 16 rows per lane), 8 rows at a time: the operands of 8 rows are
+        // requested together, behind the product (held across it, or for all 16 rows at once, they do not fit the
+        // 128 registers of 4 waves per SIMD; the other waves of the SIMD cover the wait).
+        auto epilogue = [&](int rb, const f32x16& acc) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                float xs[8], zr[8], dv[8], dg[8], ex[8];
+                int vr[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = 8 * hb + q;
+                    vr[q] = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int vc = min(vr[q], n - 1);
+                    xs[q] = p.x[(size_t)(row0 + vc) * p.ldx + col];
+                    zr[q] = 0.f; dv[q] = 0.f; dg[q] = 1.f; ex[q] = 0.f;
+                    if constexpr (STATS) {
+                        zr[q] = p.sZ[(size_t)(row0 + vc) * p.ldsz + col];
+                        if (p.s_dsc1) dv[q] = p.s_dsc1[row0 + vc];
+                    }
+                    if (need_deg) dg[q] = (float)(frp[vc + 1] - frp[vc] + p.self_loop);
+                    else if (prescale && p.self_loop) dg[q] = (float)(drp[vc + 1] - drp[vc] + p.self_loop);
+                }
+                if constexpr (STATS) {
+                    if (shuffled) {                               // workgroup-uniform: the first B rows of the batch only
+                        int gq[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) gq[q] = p.s_inv_perm[min(row0 + min(vr[q], n - 1), p.n_batch - 1)];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const float t = p.s_s2sum[gq[q]] * p.s_U[(size_t)gq[q] * p.ld_U + col];
+                            ex[q] = row0 + min(vr[q], n - 1) < p.n_batch ? t : 0.f;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int vrow = vr[q];
+                    float tot = acc[8 * hb + q];
+                    const float xv = xs[q];
+                    float wv = pro ? fmaxf(xv * psc_i + psh_i, 0.f) : xv;        // the tile's own value of this element
+                    if (p.self_loop) {
+                        if (prescale) wv = xv / dg[q];
+                        tot += wv;
+                    }
+                    if (need_deg) tot /= dg[q];                                  // 0/0 -> NaN as in the reference
+                    const float zrow = zr[q];
+                    if (!p.self_loop) {
+                        const float sb = prescale ? xv : wv;
+                        tot += selfB * sb;
+                        if constexpr (STATS) {
+                            if (p.deps_partial && !p.hfwd && vrow < n)
+                                dot += (double)(sb * fmaxf(zrow * lsc + lsh, 0.f));   // h recomputed as the forward formed it
+                        }
+                    }
+                    if constexpr (STATS) {
+                        tot += s_pb + dv[q] * s_ub;
+                        tot += ex[q];
+                        if (!(zrow * lsc + lsh > 0.f)) tot = 0.f;
+                        if (vrow < n) {
+                            ss1 += tot;
+                            ss2 += tot * (zrow - lmu);
+                        }
+                    }
+                    if (vrow < n) p.y[(size_t)(row0 + vrow) * p.ldy + col] = tot;
+                }
+            }
+        };
+        epilogue(rbA, accA);
+        if (two) epilogue(rbB, accB);
+    }
+
+    // ---- reductions (fixed order) ---------------------------------------------------------------
+    if constexpr (STATS) {
+        __syncthreads();                                          // the planes are dead: reuse them
+        double* sred = reinterpret_cast<double*>(smem);          // [8 waves][2][32]
+        double d1 = (double)ss1, d2 = (double)ss2;
+        d1 += __shfl_xor(d1, 32, 64);
+        d2 += __shfl_xor(d2, 32, 64);
+        if (h == 0) {
+            sred[(wave * 2 + 0) * 32 + i] = d1;
+            sred[(wave * 2 + 1) * 32 + i] = d2;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int which = tid >> 5, c = tid & 31;
+            double sum = 0.0;
+            for (int w = 0; w < kAggmThreads / 64; ++w) sum += sred[(w * 2 + which) * 32 + c];
+            if (which) sum *= (double)p.s_rstd[col0 + c];         // sum G (Z - mean) -> sum G xhat
+            p.s_partial[((size_t)b * 2 + which) * 64 + col0 + c] = sum;
+        }
+    }
+    if (p.deps_partial) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);
+        const double w = wave_sum_d(dot);
+        if (lane == 0) red[wave] = w;
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int k = 0; k < kAggmThreads / 64; ++k) s += red[k];
+            p.deps_partial[(size_t)b * nc + cb] = s;
+        }
+    }
+}
+
+// ---- bit adjacency ----------------------------------------------------------------------------
+// graph g: W = ceil(n / 32) words per row, 32 W rows (zero rows pad the last 32-row block); bit (k % 32) of word
+// [v][k / 32] = 1 iff k is in row v of the CSR.  dup[g] = number of CSR entries that hit a bit already set (a
+// multigraph's repeated edge: the bit matrix cannot carry its weight -- the caller keeps such graphs on the CSR path).
+extern "C" long long gnm_adj_bits_words(int n) {
+    const long long W = (n + 31) / 32;
+    return W * 32 * W;
+}
+extern "C" int gnm_aggm_max_nodes(void) { return kAggmMaxN; }
+extern "C" int gnm_aggm_num_partials(int F, int B) { return (F % 32) ? 0 : B * (F / 32); }
+
+__global__ void __launch_bounds__(256) gnm_adj_bits_build_kernel(const int32_t* rowptr, const uint16_t* colv,
+                                                                 const int64_t* g_rp_off, const int64_t* g_col_off,
+                                                                 const int32_t* g_n, uint32_t* bits,
+                                                                 const int64_t* g_bits_off, int32_t* dup) {
+    const int g = blockIdx.x;
+    const int n = g_n[g];
+    const int W = (n + 31) >> 5;
+    uint32_t* out = bits + g_bits_off[g];
+    const int words = W * 32 * W;
+    for (int k = threadIdx.x; k < words; k += blockDim.x) out[k] = 0u;
+    __syncthreads();
+    const int32_t* rp = rowptr + g_rp_off[g];
+    const uint16_t* cl = colv + g_col_off[g];
+    int ndup = 0;
+    for (int v = threadIdx.x >> 3; v < n; v += blockDim.x >> 3) {        // 8 threads per row
+        for (int e = rp[v] + (threadIdx.x & 7); e < rp[v + 1]; e += 8) {
+            const unsigned k = cl[e];
+            const unsigned bit = 1u << (k & 31);
+            const unsigned old = atomicOr(out + (size_t)v * W + (k >> 5), bit);
+            ndup += (old & bit) ? 1 : 0;
+        }
+    }
+    if (ndup) atomicAdd(dup + g, ndup);
+}
+
+extern "C" int gnm_adj_bits_build(const int32_t* rowptr, const uint16_t* col, const int64_t* g_rp_off,
+                                  const int64_t* g_col_off, const int32_t* g_n, int G, uint32_t* bits,
+                                  const int64_t* g_bits_off, int32_t* dup, void* stream) {
+    if (G <= 0) return GNM_OK;
+    if (!rowptr || !g_rp_off || !g_col_off || !g_n || !bits || !g_bits_off || !dup) return GNM_ERR_BAD_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    GNM_HIP(hipMemsetAsync(dup, 0, (size_t)G * 4, s));
+    hipLaunchKernelGGL(gnm_adj_bits_build_kernel, dim3(G), dim3(256), 0, s, rowptr, col, g_rp_off, g_col_off, g_n, bits,
+                       g_bits_off, dup);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// ---- launch -------------------------------------------------------------------------------------
+static bool aggm_shape_ok(const AggArgs& a, int n_max) {
+    if (!a.adj_bits || !a.b_bits_off) return false;
+    if (n_max < 1 || n_max > kAggmMaxN) return false;
+    if ((a.F & 31) || a.F > 256) return false;
+    if ((a.ldx & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15)) return false;
+    if (a.hfwd && ((a.ldh & 3) || (reinterpret_cast<uintptr_t>(a.hfwd) & 15))) return false;
+    return true;
+}
+
+static int launch_aggm(AggArgs a, int B, int n_max, bool stats, hipStream_t stream) {
+    a.n_graphs = B;
+    a.n16_max = ((n_max + 15) / 16) * 16;
+    const size_t lds = (size_t)3 * a.n16_max * 64 + kAggmScratch;
+    const int nc = a.F / 32;
+    const int grid = ((B + 7) / 8) * 8 * nc;
+    if (stats) {
+        GNM_ALLOW_FULL_LDS(&gnm_aggm_kernel<true>);
+        hipLaunchKernelGGL(gnm_aggm_kernel<true>, dim3(grid), dim3(kAggmThreads), lds, stream, a);
+    } else {
+        GNM_ALLOW_FULL_LDS(&gnm_aggm_kernel<false>);
+        hipLaunchKernelGGL(gnm_aggm_kernel<false>, dim3(grid), dim3(kAggmThreads), lds, stream, a);
+    }
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// gnm_agg over the bit adjacency.  Same arguments as gnm_agg plus (adj_bits, b_bits_off); the CSR arguments keep
+// their meaning (degrees come from them).  GNM_ERR_UNSUPPORTED: shape outside this kernel (n_max > 416, F not a
+// multiple of 32, unaligned rows) -- call gnm_agg.  deps_partial receives gnm_aggm_num_partials(F, B) values.
+extern "C" int gnm_aggm(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
+                        const uint32_t* adj_bits, const int64_t* b_bits_off, const int32_t* deg_rowptr,
+                        const int64_t* b_deg_off, const int32_t* node_off, int B, int n_max, const float* x, int ldx,
+                        float* y, int ldy, int F, const float* eps, int average, int self_loop, int backward,
+                        const float* hfwd, int ldh, double* deps_partial, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (F <= 0 || n_max < 0) return GNM_ERR_BAD_ARG;
+    if (deps_partial && !hfwd) return GNM_ERR_BAD_ARG;
+    AggArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
+    a.adj_bits = adj_bits; a.b_bits_off = b_bits_off;
+    a.deg_rowptr = deg_rowptr ? deg_rowptr : rowptr;
+    a.b_deg_off = b_deg_off ? b_deg_off : b_rp_off;
+    a.node_off = node_off; a.x = x; a.y = y; a.eps = eps; a.hfwd = hfwd; a.deps_partial = deps_partial;
+    a.ldx = ldx; a.ldy = ldy; a.ldh = ldh; a.F = F; a.nslices = 1;
+    a.average = average; a.self_loop = self_loop; a.backward = backward;
+    if (!aggm_shape_ok(a, n_max)) return GNM_ERR_UNSUPPORTED;
+    return launch_aggm(a, B, n_max, false, reinterpret_cast<hipStream_t>(stream));
+}
+
+// gnm_agg_bwd_stats over the bit adjacency (F == 64 only, like the CSR form).
+extern "C" int gnm_aggm_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
+                                  const int64_t* b_col_off, const uint32_t* adj_bits, const int64_t* b_bits_off,
+                                  const int32_t* deg_rowptr, const int64_t* b_deg_off, const int32_t* node_off, int B,
+                                  int n_max, const float* x, int ldx, float* y, int ldy, int F, const float* eps,
+                                  int average, int self_loop, const float* hfwd, int ldh, double* deps_partial,
+                                  const float* sZ, int ldsz, const float* s_scale, const float* s_shift,
+                                  const float* s_mean, const float* s_rstd, const float* dpool, int ld_dpool,
+                                  int graph_avg, const float* dsc1, const float* U, int ld_U, const int32_t* inv_perm,
+                                  const float* s2sum, double* s_partial, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (F != 64 || !y || !sZ || !s_partial) return GNM_ERR_UNSUPPORTED;
+    if (deps_partial && !hfwd && self_loop) return GNM_ERR_BAD_ARG;
+    AggArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
+    a.adj_bits = adj_bits; a.b_bits_off = b_bits_off;
+    a.deg_rowptr = deg_rowptr ? deg_rowptr : rowptr;
+    a.b_deg_off = b_deg_off ? b_deg_off : b_rp_off;
+    a.node_off = node_off; a.x = x; a.y = y; a.eps = eps; a.hfwd = hfwd; a.deps_partial = deps_partial;
+    a.ldx = ldx; a.ldy = ldy; a.ldh = ldh; a.F = F; a.nslices = 1;
+    a.average = average; a.self_loop = self_loop; a.backward = 1;
+    a.sZ = sZ; a.s_scale = s_scale; a.s_shift = s_shift; a.s_mean = s_mean; a.s_rstd = s_rstd;
+    a.s_dpool = dpool; a.s_dsc1 = dsc1; a.s_U = U; a.s_inv_perm = inv_perm; a.s_s2sum = s2sum;
+    a.s_partial = s_partial; a.ldsz = ldsz; a.ld_dpool = ld_dpool; a.ld_U = ld_U; a.s_avg = graph_avg;
+    a.n_batch = B;
+    if (!aggm_shape_ok(a, n_max)) return GNM_ERR_UNSUPPORTED;
+    return launch_aggm(a, B, n_max, true, reinterpret_cast<hipStream_t>(stream));
+}
+
+// gnm_agg_fwd_bnrelu over the bit adjacency (F == 64 only, like the CSR form).
+extern "C" int gnm_aggm_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
+                                   const int64_t* b_col_off, const uint32_t* adj_bits, const int64_t* b_bits_off,
+                                   const int32_t* node_off, int B, int n_max, const float* z, int ldz,
+                                   const float* scale, const float* shift, float* hout, int ldh, float* gf, int ldgf,
+                                   int graph_avg, float* y, int ldy, int F, const float* eps, int average,
+                                   int self_loop, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (F != 64 || !y || !z || !scale || !shift || !hout) return GNM_ERR_UNSUPPORTED;
+    if ((ldh & 3) || (gf && (ldgf & 3))) return GNM_ERR_UNSUPPORTED;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+                         reinterpret_cast<uintptr_t>(hout) | reinterpret_cast<uintptr_t>(gf);
+    if (al & 15) return GNM_ERR_UNSUPPORTED;
+    AggArgs a;
+    memset(&a, 0, sizeof(a));
+    a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
+    a.adj_bits = adj_bits; a.b_bits_off = b_bits_off;
+    a.deg_rowptr = rowptr; a.b_deg_off = b_rp_off;
+    a.node_off = node_off; a.x = z; a.y = y; a.eps = eps;
+    a.ldx = ldz; a.ldy = ldy; a.F = F; a.nslices = 1;
+    a.average = average; a.self_loop = self_loop; a.backward = 0;
+    a.p_scale = scale; a.p_shift = shift; a.p_hout = hout; a.p_gf = gf; a.p_ldh = ldh; a.p_ldgf = ldgf;
+    a.p_gf_avg = graph_avg;
+    if (!aggm_shape_ok(a, n_max)) return GNM_ERR_UNSUPPORTED;
+    return launch_aggm(a, B, n_max, false, reinterpret_cast<hipStream_t>(stream));
+}

@@ -1078,6 +1078,7 @@ struct LbArgs {
     int ldg, ldz, ldx, ldw, lda, ldsz;
     int N, K, H;
     int pro_relu;
+    unsigned long long* stamps;   // tuning builds only, as LinArgs::stamps
 };
 
 // NARROW: K < 32 (the first Linear of layer 0, K = F0): one zero-padded 32-column tile, guarded scalar
@@ -1105,11 +1106,14 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     float* Xs = Xs_all + wave * 32 * XS;
+    GNM_LSTAMP(0)
     for (int idx = tid; idx < HP * KP; idx += 256) {
         const int hh = idx / KP, k = idx - hh * KP;
         Wt[idx] = (!NARROW || k < p.K) ? p.W[(size_t)hh * p.ldw + k] : 0.f;
     }
     __syncthreads();
+    GNM_LSTAMP(1)
+    int tk = 0;
 
     const int c4 = lane % H4, lrow0 = lane / H4;
     // BatchNorm-backward coefficients of this lane's column chunk: kept in registers for the whole kernel, except in
@@ -1155,6 +1159,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     const int nlast = p.N - 1;
     for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
         const int r0 = t * 32;
+        GNM_LSTAMP(2 + 5 * min(tk, 11))
         // ---- all global loads of the tile first -------------------------------------
         float4 g4[NLD], z4[NLD];
 #pragma unroll
@@ -1200,6 +1205,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
                 xv[s][b] = (!NARROW || 32 * b + i < p.K) ? p.X[(size_t)grow * p.ldx + 32 * b + i] : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
+        GNM_LSTAMP(3 + 5 * min(tk, 11))
         // ---- dX = dZ W ------------------------------------------------------------------
         f32x16 dacc[KT];
         if (p.dA) {
@@ -1221,6 +1227,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
                     dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wrow[s * KP + 32 * c], dacc[c], 0, 0, 0);
             }
         }
+        GNM_LSTAMP(4 + 5 * min(tk, 11))
         // ---- dW += dZ^T f(X), db += column sums of dZ -----------------------------------
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -1249,6 +1256,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();          // everyone is done reading the dZ image
+        GNM_LSTAMP(5 + 5 * min(tk, 11))
         // ---- store dX through the staging image (16-B row-contiguous stores) ---------------
         if (p.dA) {
             if constexpr (SAMEZ) {
@@ -1326,7 +1334,10 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        GNM_LSTAMP(6 + 5 * min(tk, 11))
+        ++tk;
     }
+    GNM_LSTAMP(62)
 
     // ---- lower-BatchNorm sums: lanes with the same column chunk, then the 4 waves (fixed order) ----
     if constexpr (STATS) {
@@ -1402,6 +1413,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
         for (int w = 0; w < 4; ++w) sum += dbdump[(w * HT + a) * 64 + ii] + dbdump[(w * HT + a) * 64 + 32 + ii];
         out[(size_t)p.H * p.K + 32 * a + ii] = sum;
     }
+    GNM_LSTAMP(63)
 }
 
 template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false>
@@ -1458,6 +1470,11 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     a.G = G; a.Z = Z; a.X = X; a.W = W; a.mean = mean; a.rstd = rstd; a.cA = cA; a.m1 = m1; a.m2 = m2;
     a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dA = dA; a.partial = workspace;
     a.ldg = ldg; a.ldz = ldz; a.ldx = ldx; a.ldw = ldw; a.lda = lda; a.N = N; a.K = K; a.H = H; a.pro_relu = pro_relu;
+#ifdef GNM_LIN_TUNING
+    a.stamps = g_lin_stamps;
+#else
+    a.stamps = nullptr;
+#endif
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int grid = gnm_linear_bwd_grid(N);
     int rc = GNM_ERR_UNSUPPORTED;

@@ -27,6 +27,15 @@ SIGNATURES = {
     "gnm_agg_slice_width": (_i, [_i, _i]),
     "gnm_agg_num_partials": (_i, [_i, _i, _i]),
     "gnm_sum_partials": (_i, [_p, _i, _p, _p]),
+    "gnm_adj_bits_words": (_ll, [_i]),
+    "gnm_aggm_max_nodes": (_i, []),
+    "gnm_aggm_num_partials": (_i, [_i, _i]),
+    "gnm_adj_bits_build": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),
+    "gnm_aggm": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p]),
+    "gnm_aggm_bwd_stats": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _p, _i, _p,
+                                _p, _i, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _p, _p]),
+    "gnm_aggm_fwd_bnrelu": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _i, _p, _i, _i, _p, _i, _i, _p,
+                                 _i, _i, _p]),
     "gnm_rowdot_num_partials": (_i, []),
     "gnm_rowdot_partials": (_i, [_p, _i, _p, _i, _ll, _i, _p, _p]),
     "gnm_sum_partials_multi": (_i, [_p, _ll, _p, _i, _p, _p]),

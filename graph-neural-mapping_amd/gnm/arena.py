@@ -9,10 +9,18 @@ a batch is then just B graph ids, from which three small offset vectors are gath
 the device.
 """
 
+import os
+
 import numpy as np
 import torch
 
 from ._cabi import GnmError, check, lib
+
+# A batch takes the matrix-core aggregation (csrc/aggm.hip: bit adjacency x bf16 planes) when every graph in it has
+# a bit matrix and the batch is at least this dense (edges / nodes^2): the product costs ~n^2 per graph whatever the
+# edge count, the gather ~edges.  Measured crossover on MI355X at n = 400: ~8 % (the benchmark graphs are 30 %).
+# Tuning knob, read once: GNM_DENSE_FILL (a value > 1 turns the matrix-core path off).
+DENSE_MIN_FILL = float(os.environ.get("GNM_DENSE_FILL", "0.08"))
 
 
 class _Growable:
@@ -39,12 +47,28 @@ class _Growable:
         self.size = need
         return off
 
+    def reserve(self, k):
+        """k zeroed elements at the end (filled on the device by the caller); returns their offset"""
+        need = self.size + k
+        if need + self.slack > self.buf.shape[0]:
+            cap = max(need + self.slack, 2 * self.buf.shape[0], 1024)
+            nb = torch.zeros((cap,) if self.width is None else (cap, self.width), dtype=self.dtype, device=self.device)
+            nb[: self.size].copy_(self.buf[: self.size])
+            self.buf = nb
+        else:
+            self.buf[self.size:need].zero_()
+        off = self.size
+        self.size = need
+        return off
+
 
 class Batch:
     """What the kernels need to know about one batch of graphs (all on the device)."""
 
     __slots__ = ("B", "N", "n_max", "n_min", "nnz_max", "arena", "node_off", "rp_off", "col_off", "t_rp_off",
-                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base")
+                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base", "bits_off", "t_bits_off", "dense")
+    # dense: every graph has a bit adjacency and the batch is dense enough for the matrix-core aggregation
+    # (DENSE_MIN_FILL); bits_off / t_bits_off: int64 [B] offsets of the forward / transposed bit matrices in arena.bits
     # feat_base: int64 [B], first row of each graph's node features in the arena's feature buffer.  Part of the
     # batch (not looked up in the arena's tables at use): a captured hipGraph replays the lookup's kernels with the
     # table tensor of capture time, which is freed as soon as another graph is added to the arena.
@@ -62,6 +86,9 @@ class GraphArena:
         # branches, so 128 readable ids are kept past the last block (include/gnm_hip.h)
         self.col = _Growable(torch.int16, self.device, slack=256)
         self.feat = None                                    # created on first add (needs F0)
+        # bit adjacency of every graph small enough for csrc/aggm.hip (built on the device from the CSR at add time)
+        self.bits = _Growable(torch.int32, self.device)
+        self.bits_off, self.t_bits_off, self.bits_ok = [], [], []
         self.n, self.rp_off, self.col_off, self.t_rp_off, self.t_col_off, self.feat_off, self.nnz = [], [], [], [], [], [], []
         self.sym = []
         self._dev_tables = None
@@ -152,8 +179,56 @@ class GraphArena:
             self.n.append(n); self.nnz.append(E); self.sym.append(sym)
             self.rp_off.append(rp_off); self.col_off.append(col_off)
             self.t_rp_off.append(t_rp_off); self.t_col_off.append(t_col_off); self.feat_off.append(feat_off)
+        self._build_bits(first)
         self._dev_tables = None
         return list(range(first, len(self.n)))
+
+    def _build_bits(self, first):
+        """bit adjacency (include/gnm_hip.h, gnm_adj_bits_build) of the graphs first.. : forward, and transposed where
+        the graph is not symmetric.  Graphs too large for the matrix-core kernel, multigraphs (a repeated edge: the
+        bit cannot carry its weight) and arenas that are not on a GPU get none (bits_ok False -> CSR gather)."""
+        G = len(self.n)
+        self.bits_off += [0] * (G - first)
+        self.t_bits_off += [0] * (G - first)
+        self.bits_ok += [False] * (G - first)
+        if self.device.type != "cuda" or DENSE_MIN_FILL > 1.0:
+            return
+        nmax = int(lib.gnm_aggm_max_nodes())
+        jobs = []                       # (graph, transposed?, rp_off, col_off, n, bits_off)
+        pos = self.bits.size
+        for g in range(first, G):
+            n = self.n[g]
+            if n < 1 or n > nmax:
+                continue
+            words = int(lib.gnm_adj_bits_words(n))
+            jobs.append((g, False, self.rp_off[g], self.col_off[g], n, pos))
+            self.bits_off[g] = pos
+            pos += words
+            if self.sym[g]:
+                self.t_bits_off[g] = self.bits_off[g]
+            else:
+                jobs.append((g, True, self.t_rp_off[g], self.t_col_off[g], n, pos))
+                self.t_bits_off[g] = pos
+                pos += words
+        if not jobs:
+            return
+        off = self.bits.reserve(pos - self.bits.size)
+        assert off == jobs[0][5]
+        d = self.device
+        rp = torch.tensor([j[2] for j in jobs], dtype=torch.int64, device=d)
+        co = torch.tensor([j[3] for j in jobs], dtype=torch.int64, device=d)
+        nn = torch.tensor([j[4] for j in jobs], dtype=torch.int32, device=d)
+        bo = torch.tensor([j[5] for j in jobs], dtype=torch.int64, device=d)
+        dup = torch.empty(len(jobs), dtype=torch.int32, device=d)
+        with torch.cuda.device(d):
+            st = torch.cuda.current_stream(d).cuda_stream
+            check(lib.gnm_adj_bits_build(self.rowptr.buf.data_ptr(), self.col.buf.data_ptr(), rp.data_ptr(),
+                                         co.data_ptr(), nn.data_ptr(), len(jobs), self.bits.buf.data_ptr(),
+                                         bo.data_ptr(), dup.data_ptr(), st), "gnm_adj_bits_build")
+        dup_h = dup.cpu().numpy()
+        bad = {jobs[k][0] for k in range(len(jobs)) if dup_h[k] != 0}
+        for j in jobs:
+            self.bits_ok[j[0]] = j[0] not in bad
 
     def add_many(self, graphs, threads=None):
         """add() for a whole dataset: host CSRs built on a few threads, one upload per array.  Returns the arena
@@ -201,6 +276,10 @@ class GraphArena:
             self._dev_tables = dict(n=t(self.n, torch.int64), rp=t(self.rp_off, torch.int64),
                                     col=t(self.col_off, torch.int64), trp=t(self.t_rp_off, torch.int64),
                                     tcol=t(self.t_col_off, torch.int64), feat=t(self.feat_off, torch.int64),
+                                    bits=t(self.bits_off, torch.int64), tbits=t(self.t_bits_off, torch.int64),
+                                    bits_ok_host=np.asarray(self.bits_ok, dtype=bool),
+                                    bits_host=np.asarray(self.bits_off, dtype=np.int64),
+                                    tbits_host=np.asarray(self.t_bits_off, dtype=np.int64),
                                     n_host=np.asarray(self.n, dtype=np.int64),
                                     nnz_host=np.asarray(self.nnz, dtype=np.int64),
                                     sym_host=np.asarray(self.sym, dtype=bool),
@@ -241,7 +320,18 @@ class GraphArena:
             b.t_rp_off, b.t_col_off = b.rp_off, b.col_off
         else:
             b.t_rp_off, b.t_col_off = tb["trp"][gd], tb["tcol"][gd]
+        b.dense = self.dense_ok(gh)
+        b.bits_off = tb["bits"][gd]
+        b.t_bits_off = b.bits_off if b.symmetric else tb["tbits"][gd]
         return b
+
+    def dense_ok(self, gh):
+        """do the graphs gh (host int64 array of arena ids) form a batch for the matrix-core aggregation?"""
+        tb = self._tables()
+        if gh.shape[0] == 0 or not bool(tb["bits_ok_host"][gh].all()):
+            return False
+        ns = tb["n_host"][gh].astype(np.float64)
+        return float(tb["nnz_host"][gh].sum()) >= DENSE_MIN_FILL * float((ns * ns).sum())
 
     def _feature_rows(self, batch):
         if batch.equal_n:
@@ -340,31 +430,35 @@ class StaticBatch:
 
     def __init__(self, template):
         b = Batch()
-        for f in ("B", "N", "n_max", "n_min", "nnz_max", "arena", "symmetric", "node_off_host"):
+        for f in ("B", "N", "n_max", "n_min", "nnz_max", "arena", "symmetric", "node_off_host", "dense"):
             setattr(b, f, getattr(template, f))
         b.node_off = template.node_off.clone()
         b.rp_off, b.col_off = template.rp_off.clone(), template.col_off.clone()
         b.gids = template.gids.clone()
         b.feat_base = template.feat_base.clone()
+        b.bits_off = template.bits_off.clone()
         if template.symmetric:
-            b.t_rp_off, b.t_col_off = b.rp_off, b.col_off
+            b.t_rp_off, b.t_col_off, b.t_bits_off = b.rp_off, b.col_off, b.bits_off
         else:
             b.t_rp_off, b.t_col_off = template.t_rp_off.clone(), template.t_col_off.clone()
+            b.t_bits_off = template.t_bits_off.clone()
         self.batch = b
 
     def load(self, other):
         b = self.batch
-        if (other.B, other.N, other.n_max, other.n_min, other.symmetric) != (b.B, b.N, b.n_max, b.n_min, b.symmetric) \
-                or other.nnz_max > b.nnz_max:
+        if (other.B, other.N, other.n_max, other.n_min, other.symmetric, other.dense) != \
+                (b.B, b.N, b.n_max, b.n_min, b.symmetric, b.dense) or other.nnz_max > b.nnz_max:
             raise ValueError("StaticBatch.load: batch shape differs from the captured one")
         b.node_off.copy_(other.node_off, non_blocking=True)
         b.rp_off.copy_(other.rp_off, non_blocking=True)
         b.col_off.copy_(other.col_off, non_blocking=True)
         b.gids.copy_(other.gids, non_blocking=True)
         b.feat_base.copy_(other.feat_base, non_blocking=True)
+        b.bits_off.copy_(other.bits_off, non_blocking=True)
         if not b.symmetric:
             b.t_rp_off.copy_(other.t_rp_off, non_blocking=True)
             b.t_col_off.copy_(other.t_col_off, non_blocking=True)
+            b.t_bits_off.copy_(other.t_bits_off, non_blocking=True)
 
 
 class PackedStaticBatch:
@@ -373,10 +467,10 @@ class PackedStaticBatch:
     (gnm/graphs.py CapturedEval): assembling a Batch the general way costs ~15 tiny device ops (~150 us of host
     time), which is most of a B = 1 forward."""
 
-    def __init__(self, arena, B, n, symmetric, nnz_max):
+    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False):
         dev = arena.device
         self.arena, self.B, self.n = arena, int(B), int(n)
-        words = 6 * B + (B + 2) // 2                       # 6 int64 vectors + node_off as int32 pairs
+        words = 8 * B + (B + 2) // 2                       # 8 int64 vectors + node_off as int32 pairs
         node_off = np.arange(B + 1, dtype=np.int64) * n
         # a small ring of pinned staging buffers: the copy is asynchronous, so a buffer may only be rewritten once
         # the copy that read it has run (an event per slot; by the time a slot comes round again it has)
@@ -385,7 +479,7 @@ class PackedStaticBatch:
             h = torch.zeros(words, dtype=torch.int64)
             if dev.type == "cuda":
                 h = h.pin_memory()
-            h.numpy()[6 * B:].view(np.int32)[:B + 1] = node_off       # constant: equal-size graphs
+            h.numpy()[8 * B:].view(np.int32)[:B + 1] = node_off       # constant: equal-size graphs
             self._ring.append(h)
             self._events.append(None)
         self._dev = torch.zeros(words, dtype=torch.int64, device=dev)
@@ -393,11 +487,14 @@ class PackedStaticBatch:
         b = Batch()
         b.arena, b.B, b.N, b.n_max, b.n_min, b.nnz_max = arena, int(B), int(B * n), int(n), int(n), int(nnz_max)
         b.symmetric = bool(symmetric)
+        b.dense = bool(dense)
+        b.bits_off = dv[6 * B:7 * B]
+        b.t_bits_off = b.bits_off if symmetric else dv[7 * B:8 * B]
         b.rp_off, b.col_off = dv[0:B], dv[B:2 * B]
         b.t_rp_off, b.t_col_off = (b.rp_off, b.col_off) if symmetric else (dv[2 * B:3 * B], dv[3 * B:4 * B])
         b.gids = dv[4 * B:5 * B]
         b.feat_base = dv[5 * B:6 * B]
-        b.node_off = dv[6 * B:].view(torch.int32)[:B + 1]
+        b.node_off = dv[8 * B:].view(torch.int32)[:B + 1]
         b.node_off_host = node_off
         self.batch = b
         self._dev.copy_(self._ring[0])
@@ -408,7 +505,8 @@ class PackedStaticBatch:
         tb = self.arena._tables()
         b = self.batch
         return (gh.shape[0] == b.B and bool((tb["n_host"][gh] == self.n).all())
-                and bool(tb["sym_host"][gh].all()) == b.symmetric and int(tb["nnz_host"][gh].max()) <= b.nnz_max)
+                and bool(tb["sym_host"][gh].all()) == b.symmetric and int(tb["nnz_host"][gh].max()) <= b.nnz_max
+                and self.arena.dense_ok(gh) == b.dense)
 
     def load_gids(self, gh):
         tb = self.arena._tables()
@@ -424,6 +522,8 @@ class PackedStaticBatch:
         np.take(tb["tcol_host"], gh, out=hv[3 * B:4 * B])
         hv[4 * B:5 * B] = gh
         np.take(tb["feat_host"], gh, out=hv[5 * B:6 * B])
+        np.take(tb["bits_host"], gh, out=hv[6 * B:7 * B])
+        np.take(tb["tbits_host"], gh, out=hv[7 * B:8 * B])
         self._dev.copy_(self._ring[i], non_blocking=True)
         if self._dev.is_cuda:
             if self._events[i] is None:

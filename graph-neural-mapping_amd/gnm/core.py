@@ -157,14 +157,43 @@ class GinSpec:
         self.sync_bn = None
 
 
+def _dense(batch, F_):
+    """does this batch take the matrix-core aggregation (csrc/aggm.hip)?  The arena decides per batch (dense graphs
+    with a bit adjacency, GraphArena.batch_from_gids); the kernel wants 32-column blocks."""
+    return bool(getattr(batch, "dense", False)) and F_ % 32 == 0
+
+
+def agg_partials_capacity(batch, F_):
+    """doubles a d-eps partial buffer must hold for this batch, whichever aggregation kernel runs"""
+    k = int(lib.gnm_agg_num_partials(F_, batch.n_max, batch.B))
+    if _dense(batch, F_):
+        k = max(k, int(lib.gnm_aggm_num_partials(F_, batch.B)))
+    return k
+
+
 def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None):
-    """y = None: only the d-eps partials are produced (no gather)."""
+    """y = None: only the d-eps partials are produced (no gather).  Returns the number of d-eps partials written."""
     a = batch.arena
     if backward:
         rp_off, col_off = batch.t_rp_off, batch.t_col_off
     else:
         rp_off, col_off = batch.rp_off, batch.col_off
     tag = "agg_%s_F%d%s" % ("bwd" if backward else "fwd", F_, "_dot" if y is None else "")
+    if _dense(batch, F_):
+        bits_off = batch.t_bits_off if backward else batch.bits_off
+        with _timed(tag, F=F_, B=batch.B, N=batch.N, mfma=1) as tm:
+            rc = lib.gnm_aggm(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), rp_off.data_ptr(), col_off.data_ptr(),
+                              a.bits.buf.data_ptr(), bits_off.data_ptr(), a.rowptr.buf.data_ptr(),
+                              batch.rp_off.data_ptr(), batch.node_off.data_ptr(), batch.B, batch.n_max, x.data_ptr(),
+                              x.stride(0), ptr(y), y.stride(0) if y is not None else 0, F_, eps_ptr, int(spec.n_avg),
+                              int(not spec.learn_eps), int(backward), ptr(hfwd),
+                              hfwd.stride(0) if hfwd is not None else 0, ptr(deps_partial), _stream())
+            if rc != 0:
+                tm.cancel()
+        if rc == 0:
+            return int(lib.gnm_aggm_num_partials(F_, batch.B))
+        if rc != -2:
+            check(rc, "gnm_aggm")
     with _timed(tag, F=F_, B=batch.B, N=batch.N):
         check(lib.gnm_agg(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), rp_off.data_ptr(), col_off.data_ptr(),
                           a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), batch.B,
@@ -172,6 +201,7 @@ def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None)
                           y.stride(0) if y is not None else 0, F_,
                           eps_ptr, int(spec.n_avg), int(not spec.learn_eps), int(backward), ptr(hfwd),
                           hfwd.stride(0) if hfwd is not None else 0, ptr(deps_partial), _stream()), "gnm_agg")
+    return int(lib.gnm_agg_num_partials(F_, batch.n_max, batch.B))
 
 
 def _linear(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
@@ -232,15 +262,28 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
             if pending is not None:
                 # the previous layer's BatchNorm + ReLU + readout ride on this aggregation's tile load
                 z, scale, shift, hout, gslice = pending
-                with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1) as tm:
-                    rc = lib.gnm_agg_fwd_bnrelu(
-                        a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
-                        batch.col_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max,
-                        z.data_ptr(), z.stride(0), scale.data_ptr(), shift.data_ptr(), hout.data_ptr(),
-                        hout.stride(0), gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), pooled.data_ptr(),
-                        pooled.stride(0), F_l, eps_ptr, int(spec.n_avg), int(not spec.learn_eps), _stream())
-                    if rc != 0:
-                        tm.cancel()       # declined (or failed): no launch happened, the fallback below times itself
+                rc = -2
+                if _dense(batch, F_l):
+                    with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1, mfma=1) as tm:
+                        rc = lib.gnm_aggm_fwd_bnrelu(
+                            a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
+                            batch.col_off.data_ptr(), a.bits.buf.data_ptr(), batch.bits_off.data_ptr(),
+                            batch.node_off.data_ptr(), B, batch.n_max, z.data_ptr(), z.stride(0), scale.data_ptr(),
+                            shift.data_ptr(), hout.data_ptr(), hout.stride(0), gslice.data_ptr(), g_f.stride(0),
+                            int(spec.g_avg), pooled.data_ptr(), pooled.stride(0), F_l, eps_ptr, int(spec.n_avg),
+                            int(not spec.learn_eps), _stream())
+                        if rc != 0:
+                            tm.cancel()
+                if rc == -2:
+                    with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1) as tm:
+                        rc = lib.gnm_agg_fwd_bnrelu(
+                            a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
+                            batch.col_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max,
+                            z.data_ptr(), z.stride(0), scale.data_ptr(), shift.data_ptr(), hout.data_ptr(),
+                            hout.stride(0), gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), pooled.data_ptr(),
+                            pooled.stride(0), F_l, eps_ptr, int(spec.n_avg), int(not spec.learn_eps), _stream())
+                        if rc != 0:
+                            tm.cancel()       # declined (or failed): no launch happened, the fallback below times itself
                 if rc == -2:
                     readout(*pending)
                 else:
@@ -478,7 +521,7 @@ class GinInfoMaxFn(torch.autograd.Function):
         if spec.learn_eps:
             deps = sink["eps"] if sink is not None else torch.empty(L, **f32)
             # fp64 partials of d eps[l] from the L aggregation backwards, summed by ONE launch at the end
-            eps_stride = max([int(lib.gnm_agg_num_partials(sv_[0].shape[1], batch.n_max, B)) for sv_ in saved] +
+            eps_stride = max([agg_partials_capacity(batch, sv_[0].shape[1]) for sv_ in saved] +
                              [int(lib.gnm_rowdot_num_partials())])
             eps_parts = torch.empty((L, eps_stride), dtype=torch.float64, device=dev)
         dH_next = None
@@ -604,21 +647,41 @@ class GinInfoMaxFn(torch.autograd.Function):
                     dplo = dph[l - 1]
                     spart = torch.empty((B, 2, F_l), dtype=torch.float64, device=dev)
                     a = batch.arena
-                    with _timed("agg_bwd_F%d" % F_l, F=F_l, B=B, N=N, fused_stats=1) as tm:
-                        rc = lib.gnm_agg_bwd_stats(
-                            a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
-                            batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
-                            batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, dpooled.data_ptr(),
-                            dpooled.stride(0), dh.data_ptr(), dh.stride(0), F_l, eps_ptr, int(spec.n_avg),
-                            int(not spec.learn_eps), None, 0,      # h_in is recomputed from lo.z in the epilogue (d eps)
-                            ptr(part), lo.z.data_ptr(), lo.z.stride(0),
-                            lo.scale.data_ptr(), lo.shift.data_ptr(), lo.mean.data_ptr(), lo.rstd.data_ptr(),
-                            ptr(dplo), dplo.stride(0) if dplo is not None else 0, int(spec.g_avg),
-                            ptr(dsc1) if use_disc else None, ptr(Ulo), U.stride(0) if use_disc else 0,
-                            ptr(inv_perm) if use_disc else None, ptr(s2sum) if use_disc else None, spart.data_ptr(),
-                            st)
-                        if rc != 0:
-                            tm.cancel()
+                    rc = -2
+                    if _dense(batch, F_l):
+                        with _timed("agg_bwd_F%d" % F_l, F=F_l, B=B, N=N, fused_stats=1, mfma=1) as tm:
+                            rc = lib.gnm_aggm_bwd_stats(
+                                a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
+                                batch.t_col_off.data_ptr(), a.bits.buf.data_ptr(), batch.t_bits_off.data_ptr(),
+                                a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), B,
+                                batch.n_max, dpooled.data_ptr(), dpooled.stride(0), dh.data_ptr(), dh.stride(0), F_l,
+                                eps_ptr, int(spec.n_avg), int(not spec.learn_eps), None, 0, ptr(part),
+                                lo.z.data_ptr(), lo.z.stride(0), lo.scale.data_ptr(), lo.shift.data_ptr(),
+                                lo.mean.data_ptr(), lo.rstd.data_ptr(), ptr(dplo),
+                                dplo.stride(0) if dplo is not None else 0, int(spec.g_avg),
+                                ptr(dsc1) if use_disc else None, ptr(Ulo), U.stride(0) if use_disc else 0,
+                                ptr(inv_perm) if use_disc else None, ptr(s2sum) if use_disc else None,
+                                spart.data_ptr(), st)
+                            if rc != 0:
+                                tm.cancel()
+                        if rc == 0 and spec.learn_eps:
+                            eps_counts[l] = int(lib.gnm_aggm_num_partials(F_l, B))
+                    if rc == -2:
+                        with _timed("agg_bwd_F%d" % F_l, F=F_l, B=B, N=N, fused_stats=1) as tm:
+                            rc = lib.gnm_agg_bwd_stats(
+                                a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
+                                batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, dpooled.data_ptr(),
+                                dpooled.stride(0), dh.data_ptr(), dh.stride(0), F_l, eps_ptr, int(spec.n_avg),
+                                int(not spec.learn_eps), None, 0,      # h_in is recomputed from lo.z in the epilogue (d eps)
+                                ptr(part), lo.z.data_ptr(), lo.z.stride(0),
+                                lo.scale.data_ptr(), lo.shift.data_ptr(), lo.mean.data_ptr(), lo.rstd.data_ptr(),
+                                ptr(dplo), dplo.stride(0) if dplo is not None else 0, int(spec.g_avg),
+                                ptr(dsc1) if use_disc else None, ptr(Ulo), U.stride(0) if use_disc else 0,
+                                ptr(inv_perm) if use_disc else None, ptr(s2sum) if use_disc else None, spart.data_ptr(),
+                                st)
+                            if rc != 0:
+                                tm.cancel()
                     if rc == 0:
                         fused = True
                         pre_outer = (dh, spart, B)
@@ -632,8 +695,10 @@ class GinInfoMaxFn(torch.autograd.Function):
                                                       h_in.stride(0), N, F_l, part.data_ptr(), st),
                               "gnm_rowdot_partials")
                 elif not fused:
-                    _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True,
-                         hfwd=h_in if spec.learn_eps else None, deps_partial=part)
+                    cnt = _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True,
+                               hfwd=h_in if spec.learn_eps else None, deps_partial=part)
+                    if spec.learn_eps:
+                        eps_counts[l] = cnt
                 if l > 0:
                     dH_next = dh
                 else:

@@ -59,7 +59,7 @@ class CapturedTrainStep:
     def _arena_buffers(self):
         """addresses the captured kernels read the graph pool from: adding graphs may re-allocate them"""
         a = self.static.batch.arena
-        return (a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), a.feat.buf.data_ptr(),
+        return (a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), a.feat.buf.data_ptr(), a.bits.buf.data_ptr(),
                 tuple(sorted((k, v["buf"].data_ptr()) for k, v in a._agg0.items() if v["buf"] is not None)))
 
     def _step(self):
@@ -110,7 +110,8 @@ class CapturedEval:
         nnz = int(tb["nnz_host"][gh].max())
         nnz_cap = max(4096, 1 << (nnz - 1).bit_length()) if nnz > 0 else 4096     # launch parameters sized for this
         self.model = model
-        self.static = PackedStaticBatch(arena, gh.shape[0], n, bool(tb["sym_host"][gh].all()), nnz_cap)
+        self.static = PackedStaticBatch(arena, gh.shape[0], n, bool(tb["sym_host"][gh].all()), nnz_cap,
+                                        dense=arena.dense_ok(gh))
         self.static.load_gids(gh)
         dev = arena.device
         B = gh.shape[0]
@@ -132,7 +133,7 @@ class CapturedEval:
 
     def _arena_buffers(self):
         a = self.static.arena
-        return (a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), a.feat.buf.data_ptr(),
+        return (a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), a.feat.buf.data_ptr(), a.bits.buf.data_ptr(),
                 tuple(sorted((k, v["buf"].data_ptr()) for k, v in a._agg0.items() if v["buf"] is not None)))
 
     def _forward(self):

@@ -105,6 +105,44 @@ int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, const int64_t
 int gnm_agg_slice_width(int F, int n_max);          /* feature-slice width the kernel will use (0: unsupported) */
 int gnm_agg_num_partials(int F, int n_max, int B);  /* doubles written to deps_partial */
 int gnm_sum_partials(const double* partial, int count, float* out, void* stream);
+
+/* ---- neighbour aggregation on the matrix cores (dense graphs) --------------------------
+ * The same three operations over a BIT adjacency: y = A x as MFMA products of the 0/1 matrix with three bf16 planes
+ * of x (x split by truncation, every product exact: fp32-faithful like the gather).  Pays when the graphs are dense
+ * (the 400-node benchmark graphs are 30 % dense: ~3x the gather); the caller chooses per batch.
+ * Bit matrix of one graph with n nodes: W = ceil(n / 32) words per row, 32 W rows (zero rows pad the last block),
+ * bit (k % 32) of word [v][k / 32] = 1 iff k is a neighbour in row v of that graph's CSR: gnm_adj_bits_words(n)
+ * words at adj_bits + b_bits_off[b].  Built on the device from the arena's CSR by gnm_adj_bits_build, which also
+ * counts, per graph, CSR entries that repeat an edge (dup[g] > 0: a multigraph -- the bit matrix cannot carry the
+ * multiplicity, keep that graph on gnm_agg).  Pass the bit matrix of the TRANSPOSED CSR for backward = 1.
+ * All other arguments: exactly as in gnm_agg / gnm_agg_bwd_stats / gnm_agg_fwd_bnrelu (rowptr and the offsets are
+ * still read: degrees).  deps_partial receives gnm_aggm_num_partials(F, B) doubles.
+ * GNM_ERR_UNSUPPORTED (nothing launched; use the CSR form): n_max > gnm_aggm_max_nodes(), F not a multiple of 32
+ * (the fused forms: F != 64), rows of x not 16-byte aligned. */
+long long gnm_adj_bits_words(int n);
+int gnm_aggm_max_nodes(void);
+int gnm_aggm_num_partials(int F, int B);
+int gnm_adj_bits_build(const int32_t* rowptr, const uint16_t* col, const int64_t* g_rp_off, const int64_t* g_col_off,
+                       const int32_t* g_n, int G, uint32_t* bits, const int64_t* g_bits_off, int32_t* dup,
+                       void* stream);
+int gnm_aggm(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
+             const uint32_t* adj_bits, const int64_t* b_bits_off, const int32_t* deg_rowptr, const int64_t* b_deg_off,
+             const int32_t* node_off, int B, int n_max, const float* x, int ldx, float* y, int ldy, int F,
+             const float* eps, int average, int self_loop, int backward, const float* hfwd, int ldh,
+             double* deps_partial, void* stream);
+int gnm_aggm_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
+                       const uint32_t* adj_bits, const int64_t* b_bits_off, const int32_t* deg_rowptr,
+                       const int64_t* b_deg_off, const int32_t* node_off, int B, int n_max, const float* x, int ldx,
+                       float* y, int ldy, int F, const float* eps, int average, int self_loop, const float* hfwd,
+                       int ldh, double* deps_partial, const float* sZ, int ldsz, const float* s_scale,
+                       const float* s_shift, const float* s_mean, const float* s_rstd, const float* dpool,
+                       int ld_dpool, int graph_avg, const float* dsc1, const float* U, int ld_U,
+                       const int32_t* inv_perm, const float* s2sum, double* s_partial, void* stream);
+int gnm_aggm_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
+                        const uint32_t* adj_bits, const int64_t* b_bits_off, const int32_t* node_off, int B, int n_max,
+                        const float* z, int ldz, const float* scale, const float* shift, float* hout, int ldh,
+                        float* gf, int ldgf, int graph_avg, float* y, int ldy, int F, const float* eps, int average,
+                        int self_loop, void* stream);
 /* d eps[l] = sum_v dpooled[v,:] . h[v,:] (graphcnn.py:161) without the gather, for a layer whose aggregation
  * backward has no other consumer: gnm_rowdot_num_partials() fp64 partials, to be summed like gnm_agg's. */
 int gnm_rowdot_num_partials(void);

@@ -78,6 +78,7 @@ def test_agg_forward_backward(sizes, density, F, symmetric, average, learn_eps):
     graphs = random_graphs(rng, sizes, density, symmetric)
     ar = GraphArena(DEV)
     batch = ar.batch(graphs)
+    batch.dense = False              # this test is about the CSR gather kernels (the matrix-core path: test_gpu_aggm.py)
     assert batch.symmetric == (symmetric or density == 0.0)
     A = dense_adj(graphs)
     N = batch.N
@@ -127,7 +128,8 @@ def test_agg_forward_backward(sizes, density, F, symmetric, average, learn_eps):
         assert abs(out.item() - want) <= 1e-6 * scale        # fp64 accumulation: far below fp32 noise
 
 
-@pytest.mark.parametrize("sizes,density", [([40, 40, 40], 0.3), ([400, 400], 0.3), ([64] * 9, 0.5)])
+@pytest.mark.parametrize("sizes,density", [([40, 40, 40], 0.3), ([400, 400], 0.3), ([64] * 9, 0.5), ([3] * 50, 0.9),
+                                           ([9, 2, 12], 0.5)])
 @pytest.mark.parametrize("average,learn_eps,graph_avg,disc", [(0, 1, 0, True), (1, 1, 1, True), (0, 0, 0, False),
                                                               (1, 0, 1, True)])
 def test_agg_backward_fused_with_bn_stats(sizes, density, average, learn_eps, graph_avg, disc):
@@ -140,6 +142,7 @@ def test_agg_backward_fused_with_bn_stats(sizes, density, average, learn_eps, gr
     graphs = random_graphs(rng, sizes, density, True)
     ar = GraphArena(DEV)
     batch = ar.batch(graphs)
+    batch.dense = False              # CSR kernels on both sides of the comparison
     N, B, F = batch.N, batch.B, 64
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     dp = t(rng.standard_normal((N, F)).astype(np.float32))

@@ -7,6 +7,7 @@ HIP events, canonical GB/s and graph-layers/s, for the launch f
   bwd       gnm_agg backward with the d-eps dot product on the way in
   bwdstats  gnm_agg_bwd_stats (backward + the layer below's BatchNorm-backward pass 1: what a step's backward runs)
   phasea    y = null: tile load + barrier only
+  mplain / mfused / mbwdstats   the same three launch forms on the matrix-core kernel (csrc/aggm.hip, bit adjacency)
 
   python tools/bench_agg.py --modes plain,fused,bwdstats [--cold]
 --cold streams 1 GiB between launches so inputs come from HBM, not from the Infinity Cache."""
@@ -51,7 +52,8 @@ def main():
     y = torch.empty(N, F, device=dev)
     eps = torch.zeros(1, device=dev)
     spec = core.GinSpec(5, 2, True, "sum", "sum")
-    part = torch.empty(core.lib.gnm_agg_num_partials(F, batch.n_max, B), dtype=torch.float64, device=dev)
+    part = torch.empty(max(core.lib.gnm_agg_num_partials(F, batch.n_max, B), core.lib.gnm_aggm_num_partials(F, B)),
+                       dtype=torch.float64, device=dev)
     sc, sh = torch.rand(F, device=dev) + 0.5, torch.randn(F, device=dev) * 0.3
     mu, rs = torch.randn(F, device=dev) * 0.1, torch.rand(F, device=dev) + 0.5
     gf = torch.empty(B, F, device=dev)
@@ -86,6 +88,29 @@ def main():
                                    None if mode == "phasea" else y.data_ptr(), 0 if mode == "phasea" else F, F,
                                    eps.data_ptr(), 0, 0, int(bw), h.data_ptr() if bw else None, F if bw else 0,
                                    part.data_ptr() if bw else None, st), "gnm_agg")
+            return
+        if mode == "mplain":
+            core.check(lib.gnm_aggm(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
+                                    batch.col_off.data_ptr(), a.bits.buf.data_ptr(), batch.bits_off.data_ptr(),
+                                    a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), B,
+                                    batch.n_max, x.data_ptr(), F, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, 0, None, 0,
+                                    None, st), "gnm_aggm")
+            return
+        if mode == "mfused":
+            core.check(lib.gnm_aggm_fwd_bnrelu(
+                a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
+                a.bits.buf.data_ptr(), batch.bits_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max,
+                x.data_ptr(), F, sc.data_ptr(), sh.data_ptr(), h.data_ptr(), F, gf.data_ptr(), F, 0, y.data_ptr(), F, F,
+                eps.data_ptr(), 0, 0, st), "gnm_aggm_fwd_bnrelu")
+            return
+        if mode == "mbwdstats":
+            core.check(lib.gnm_aggm_bwd_stats(
+                a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(), batch.t_col_off.data_ptr(),
+                a.bits.buf.data_ptr(), batch.t_bits_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
+                batch.node_off.data_ptr(), B, batch.n_max, x.data_ptr(), F, y.data_ptr(), F, F, eps.data_ptr(), 0, 0,
+                None, 0, part.data_ptr(), h.data_ptr(), F, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(),
+                dpool.data_ptr(), F, 0, dsc1.data_ptr(), U.data_ptr(), F, inv_perm.data_ptr(), s2sum.data_ptr(),
+                spart.data_ptr(), st), "gnm_aggm_bwd_stats")
             return
         if mode == "fused":
             core.check(lib.gnm_agg_fwd_bnrelu(

@@ -1,9 +1,17 @@
 #!/usr/bin/env python3
-"""In-kernel timeline of the pipelined Linear forward (tuning build with -DGNM_LIN_TUNING):
-    GNM_HIP_LIB=graph-neural-mapping_amd/lib/variants/lintune.so python tools/lin_timeline.py
-stamps per wave: 0 entry, 1 weight staged (barrier), per tile t: 2+4t start, 3+4t operands in registers (X staged,
-A fragments read, next tile's loads issued), 4+4t MFMAs done, 5+4t tile stored; 62 tile loop left (the BatchNorm-statistics
-combine that follows is not stamped)."""
+"""In-kernel timeline of the Linear kernels at the headline shape (tuning build with -DGNM_LIN_TUNING):
+    python tools/build_variant.py lintune -DGNM_LIN_TUNING
+    GNM_HIP_LIB=graph-neural-mapping_amd/lib/variants/lintune.so python tools/lin_timeline.py [--kernel fwd|bwd|bwd_first]
+Lane 0 of every wave stores s_memtime at fixed points.  The counter is per XCD and its rate is not the shader clock:
+only differences inside one workgroup are used, and phases are reported as shares of the wave's lifetime next to the
+HIP-event duration of the same launch.
+
+fwd (gnm_lin_stream_kernel / gnm_lin_fast_kernel): 0 entry, 1 weight staged, per tile t: 2+4t start, 3+4t operands in
+  registers (X staged, A fragments read, next tile's loads issued), 4+4t MFMAs done, 5+4t tile stored; 62 loop left.
+bwd (gnm_linear_bwd_fused_kernel): 0 entry, 1 weight staged, per tile t: 2+5t start, 3+5t dZ tile staged (G and Z
+  arrived) and X loads issued, 4+5t dgrad MFMAs done, 5+5t wgrad MFMAs done, 6+5t dX stored; 62 loop left, 63 exit
+  (dW / BatchNorm partials written)."""
+import argparse
 import ctypes as C
 import os
 import sys
@@ -15,24 +23,44 @@ import torch
 
 from gnm import core
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--kernel", default="fwd", choices=["fwd", "bwd", "bwd_first"])
+args = ap.parse_args()
 lib = core.lib
 lib.gnm_debug_set_lin_stamps.argtypes = [C.c_void_p]
 lib.gnm_debug_set_lin_stamps.restype = None
 dev = torch.device("cuda:0")
 N, K, H = 409600, 64, 64
-x = torch.randn(N, K, device=dev)
-W = torch.randn(H, K, device=dev) * 0.1
-b = torch.randn(H, device=dev)
-z = torch.empty(N, H, device=dev)
-sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
-grid = lib.gnm_linear_grid(N)
-stats = torch.empty(grid, 2, H, dtype=torch.float64, device=dev)
+f32 = dict(dtype=torch.float32, device=dev)
+x, g, z, zlo = torch.randn(N, K, **f32), torch.randn(N, H, **f32), torch.randn(N, H, **f32), torch.randn(N, K, **f32)
+W, b = torch.randn(H, K, **f32) * 0.1, torch.randn(H, **f32)
+out, dA = torch.empty(N, H, **f32), torch.empty(N, K, **f32)
+sc, sh = torch.rand(K, **f32) + 0.5, torch.randn(K, **f32) * 0.1
+mean, rstd, cA, m1, m2 = (torch.randn(H, **f32) * 0.1, torch.rand(H, **f32) + 0.5, torch.rand(H, **f32),
+                          torch.randn(H, **f32) * 0.01, torch.randn(H, **f32) * 0.01)
+lmean, lrstd = torch.randn(K, **f32) * 0.1, torch.rand(K, **f32) + 0.5
+dW, db = torch.empty(H, K, **f32), torch.empty(H, **f32)
 st = torch.cuda.current_stream().cuda_stream
+fwd = args.kernel == "fwd"
+grid = lib.gnm_linear_grid(N) if fwd else lib.gnm_linear_bwd_grid(N)
+stats = torch.empty(grid, 2, H, dtype=torch.float64, device=dev)
+ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, H, K)), **f32)
+lp = torch.empty(grid, 2, K, dtype=torch.float64, device=dev)
 
 
 def run():
-    core.check(lib.gnm_linear_fwd(x.data_ptr(), K, W.data_ptr(), K, 0, b.data_ptr(), z.data_ptr(), H, N, K, H,
-                                  sc.data_ptr(), sh.data_ptr(), 1, stats.data_ptr(), st), "lin")
+    if fwd:
+        core.check(lib.gnm_linear_fwd(x.data_ptr(), K, W.data_ptr(), K, 0, b.data_ptr(), out.data_ptr(), H, N, K, H,
+                                      sc.data_ptr(), sh.data_ptr(), 1, stats.data_ptr(), st), "lin")
+        return
+    second = args.kernel == "bwd"
+    core.check(lib.gnm_linear_bwd_fused(
+        g.data_ptr(), H, z.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+        (zlo if second else x).data_ptr(), K, sc.data_ptr() if second else None, sh.data_ptr() if second else None,
+        1 if second else 0, W.data_ptr(), K, dA.data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, K, H,
+        zlo.data_ptr() if second else None, K if second else 0, sc.data_ptr() if second else None,
+        sh.data_ptr() if second else None, lmean.data_ptr() if second else None, lrstd.data_ptr() if second else None,
+        lp.data_ptr() if second else None, st), "bwd")
 
 
 for _ in range(5):
@@ -45,24 +73,29 @@ e0.record(); run(); e1.record(); torch.cuda.synchronize()
 lib.gnm_debug_set_lin_stamps(None)
 ms = e0.elapsed_time(e1)
 s = stamps.cpu().numpy().reshape(grid, 4, 64).astype(np.float64)
-wave_ticks = (s[:, :, 62] - s[:, :, 0])
-blk_ticks = s[:, :, 62].max(1) - s[:, :, 0].min(1)
-nt = int((s[0, 0, 2:62:4] > 0).sum())
-blocks_per_cu = grid / 256.0
-print("launch %.1f us (stamped), grid %d (%.1f blocks per CU resident together), %d tiles per wave" % (ms * 1e3, grid, blocks_per_cu, nt))
-ghz = blk_ticks.mean() / (ms * 1e6)       # all blocks co-resident: a block lives for (almost) the whole launch
-us = lambda t: t / (ghz * 1e3)
-print("clock ~ %.2f GHz (block lifetime = launch)" % ghz)
-print("  weight staging + barrier     %6.2f us" % us((s[:, :, 1] - s[:, :, 0]).mean()))
-tot = {"stage": 0.0, "mfma": 0.0, "store": 0.0, "gap": 0.0}
-for t in range(nt):
-    tot["stage"] += (s[:, :, 3 + 4 * t] - s[:, :, 2 + 4 * t]).mean()
-    tot["mfma"] += (s[:, :, 4 + 4 * t] - s[:, :, 3 + 4 * t]).mean()
-    tot["store"] += (s[:, :, 5 + 4 * t] - s[:, :, 4 + 4 * t]).mean()
-    if t + 1 < nt:
-        tot["gap"] += (s[:, :, 2 + 4 * (t + 1)] - s[:, :, 5 + 4 * t]).mean()
-print("  per wave, over its %d tiles:" % nt)
-print("    wait for X + stage + read A  %6.2f us  (%.2f per tile)" % (us(tot["stage"]), us(tot["stage"]) / nt))
-print("    64 MFMAs (+ B from LDS)      %6.2f us  (%.2f per tile; 64 x 64 cycles alone = %.2f)" % (us(tot["mfma"]), us(tot["mfma"]) / nt, 4096 / (ghz * 1e3)))
-print("    epilogue + stores            %6.2f us  (%.2f per tile)" % (us(tot["store"]), us(tot["store"]) / nt))
-print("  wave total                   %6.2f us ; idle wrt block's last wave %.2f us" % (us(wave_ticks.mean()), us((s[:, :, 62].max(1, keepdims=True) - s[:, :, 62]).mean())))
+per = 4 if fwd else 5
+names = (["wait for X + stage + read A", "64 MFMAs (+ B from LDS)", "epilogue + stores"] if fwd else
+         ["wait for G, Z + dZ tile to LDS + issue X loads", "dgrad: 64 MFMAs", "wgrad: wait for X + 64 MFMAs",
+          "mask / statistics / dX stores"])
+ntile = (s[:, :, 2:2 + per * 12:per] > 0).sum(2)                  # tiles stamped per wave (first 12 at most)
+life = s[:, :, 62] - s[:, :, 0]
+print("%s: launch %.1f us (stamped build), grid %d, tiles per wave %d..%d" % (args.kernel, ms * 1e3, grid, ntile.min(), ntile.max()))
+print("  shares of a wave's lifetime (entry -> tile loop left), mean over waves:")
+print("    weight staging + barrier                        %5.1f %%" % (100 * ((s[:, :, 1] - s[:, :, 0]) / life).mean()))
+tot = np.zeros((len(names) + 1,) + life.shape)
+for t in range(12):
+    ok = s[:, :, 2 + per * t] > 0
+    for k in range(len(names)):
+        tot[k] += np.where(ok, s[:, :, 3 + per * t + k] - s[:, :, 2 + per * t + k], 0.0)
+    if t + 1 < 12:
+        ok2 = ok & (s[:, :, 2 + per * (t + 1)] > 0)
+        tot[-1] += np.where(ok2, s[:, :, 2 + per * (t + 1)] - s[:, :, 2 + per * t + len(names)], 0.0)
+for k, nm in enumerate(names):
+    print("    %-47s %5.1f %%" % (nm, 100 * (tot[k] / life).mean()))
+print("    %-47s %5.1f %%" % ("between tiles", 100 * (tot[-1] / life).mean()))
+last = s[:, :, 62].max(1, keepdims=True)
+print("    idle until the block's last wave leaves the loop  %5.1f %% (in addition)" % (100 * ((last - s[:, :, 62]) / life).mean()))
+if not fwd:
+    print("    loop left -> kernel exit (dW / statistics combine)  %5.1f %% (in addition)" % (100 * ((s[:, :, 63] - s[:, :, 62]) / life).mean()))
+blk = s[:, :, 62].max(1) - s[:, :, 0].min(1)
+print("  block lifetime spread (ticks): min %.0f median %.0f max %.0f" % (blk.min(), np.median(blk), blk.max()))
