@@ -28,21 +28,38 @@
 // The row-block -> wave map is static, so every reduction (column statistics, d eps, readout) has a fixed order.
 #include "gnm_agg_args.h"
 #include <string.h>
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static constexpr int kAggmThreads = 512;
-static constexpr int kAggmMaxN = 416;            // 3 planes x 416 x 32 x 2 B + table + scratch: two workgroups per CU
+static constexpr int kAggmMaxN = 416;            // 13 row blocks; up to 400 nodes two workgroups share a CU's LDS
 static constexpr int kAggmScratch = 128 + 1024;  // nibble table + readout partials
+// plane layout: [k / 8][32 columns][8 consecutive k] bf16, 528 bytes per k-group (512 + 16 of padding: the 8-byte
+// transposing writes of phase A then spread over all banks; the 16-byte reads of phase B are lane-linear either way)
+static constexpr unsigned kAggmK8Stride = 528;
+static constexpr unsigned kAggmStepBytes = 2 * kAggmK8Stride;    // one 16-node MFMA step = two k-groups
+
+#ifdef GNM_AGG16_TUNING       // in-kernel timeline (tools/aggm_timeline.py)
+static unsigned long long* g_aggm_stamps = nullptr;
+extern "C" void gnm_debug_set_aggm_stamps(void* p) { g_aggm_stamps = reinterpret_cast<unsigned long long*>(p); }
+#define GNM_MSTAMP(k)                                                                                         \
+    if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
+        p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define GNM_MSTAMP(k)
+#endif
 
 __device__ __forceinline__ unsigned bf16_pair_hi(unsigned lo_word, unsigned hi_word) {
     // (top 16 bits of hi_word) : (top 16 bits of lo_word)
     return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
 }
 
-template <bool STATS>
+// AVG: neighbor_pooling_type "average" (the epilogue then also loads degrees / the raw input); decided by the launcher
+// so that the "sum" forms carry none of it.
+template <bool STATS, bool AVG>
 __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- which graph / column block: the blocks of one graph sit 8 apart, i.e. on the same XCD (one L2 serves the
@@ -55,6 +72,13 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     const int row0 = p.node_off[b];
     const int n = p.node_off[b + 1] - row0;
     const int col0 = cb * 32;
+    if (n <= 0) {            // an empty graph: no rows to write, its reductions are empty sums
+        const int t = threadIdx.x;
+        if (p.p_scale && p.p_gf && t < 32) p.p_gf[(size_t)b * p.p_ldgf + col0 + t] = p.p_gf_avg ? 0.f / 0.f : 0.f;
+        if (STATS && t < 64) p.s_partial[((size_t)b * 2 + (t >> 5)) * 64 + col0 + (t & 31)] = 0.0;
+        if (p.deps_partial && t == 0) p.deps_partial[(size_t)b * nc + cb] = 0.0;
+        return;
+    }
     const int W = (n + 31) >> 5;                                 // words per bit row = 32-row blocks
     const int ksteps = (n + 15) >> 4;
     const int n16 = ksteps * 16;
@@ -62,14 +86,36 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    const unsigned plane_bytes = (unsigned)p.n16_max * 64u;       // one plane: [n16_max / 8][32][8] bf16
+    const unsigned plane_bytes = (unsigned)(p.n16_max >> 3) * kAggmK8Stride;
     char* lut = smem + 3u * plane_bytes;
     float4* rsum = reinterpret_cast<float4*>(lut + 128);
-    const bool prescale = p.backward && p.average;
+    const bool prescale = AVG && p.backward;
     const bool pro = !STATS && p.p_scale != nullptr;
     const bool dot_a = p.deps_partial && p.hfwd;
     const int32_t* drp = p.deg_rowptr + p.b_deg_off[b];
 
+    GNM_MSTAMP(0)
+    // This wave's output row blocks and their adjacency bits: requested first, so they arrive under phase A (the
+    // timeline of the first version showed every wave waiting ~20 % of the workgroup's life for them behind the barrier)
+    const int role = (wave + cb) & 7;                           // rotate with the column block: evens out the SIMDs
+    const int rbA = role, rbB = role + 8;
+    const bool two = rbB < W;
+    const bool has_rows = p.y && rbA < W;
+    // (rows are padded to whole 16-byte pieces: four coalescing-friendly loads per row instead of 13 scattered ones,
+    //  which cost ~30 % of the workgroup's life in address processing)
+    const int WP = (W + 3) & ~3;
+    u32x4 wa[4], wb[4];
+    {
+        const uint32_t* gbits = p.adj_bits + p.b_bits_off[b];
+        const u32x4* ra = reinterpret_cast<const u32x4*>(gbits + (size_t)(min(rbA, W - 1) * 32 + i) * WP);
+        const u32x4* rb = reinterpret_cast<const u32x4*>(gbits + (size_t)((two ? rbB : min(rbA, W - 1)) * 32 + i) * WP);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const u32x4 z4 = {0u, 0u, 0u, 0u};
+            wa[d] = 4 * d < WP ? ra[d] : z4;
+            wb[d] = 4 * d < WP ? rb[d] : z4;
+        }
+    }
     if (tid < 16) {          // nibble e -> bf16 (bit 0, bit 1, bit 2, bit 3) as two words
         const unsigned one = 0x3F80u;
         u32x2 v;
@@ -97,13 +143,19 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         const int it = tid + u * kAggmThreads;
         const int rq = it >> 3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * rq + r;
-            v[u][r] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (it < nitems && row < n)
-                v[u][r] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + row) * p.ldx + col0 + 4 * c4);
-        }
+        for (int r = 0; r < 4; ++r)       // unconditional (clamped to the graph's last row; masked below): no branches
+            v[u][r] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + min(4 * rq + r, n - 1)) * p.ldx + col0 + 4 * c4);
     }
+    // the bit rows (older in the memory queue than the tile loads just issued), packed to the bytes this half-wave
+    // uses: byte m of pk[j] = step 4 j + m
+    const unsigned bsel = h ? 0x07050301u : 0x06040200u;
+    unsigned pkA[7], pkB[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        pkA[j] = __builtin_amdgcn_perm(wa[j >> 1][2 * (j & 1) + 1], wa[j >> 1][2 * (j & 1)], bsel);
+        pkB[j] = __builtin_amdgcn_perm(wb[j >> 1][2 * (j & 1) + 1], wb[j >> 1][2 * (j & 1)], bsel);
+    }
+    GNM_MSTAMP(1)
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
         const int it = tid + u * kAggmThreads;
@@ -112,7 +164,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * rq + r;
-                float4 w = v[u][r];
+                float4 w = row < n ? v[u][r] : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (row < n) {
                     if (dot_a) {
                         const float4 hh = *reinterpret_cast<const float4*>(p.hfwd + (size_t)(row0 + row) * p.ldh + col0 + 4 * c4);
@@ -136,7 +188,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                 v[u][r] = w;
             }
             // three planes by truncation; element (row 4 rq + r, column 4 c4 + c) -> plane word index below
-            const unsigned base = (unsigned)((((rq >> 1) * 32 + 4 * c4) * 8 + 4 * (rq & 1)) * 2);   // bytes, column 4 c4
+            const unsigned base = (unsigned)(rq >> 1) * kAggmK8Stride + (unsigned)((4 * c4 * 8 + 4 * (rq & 1)) * 2);   // bytes, column 4 c4
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 unsigned x0[4], x1[4], x2[4];
@@ -168,6 +220,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         }
         if (lane < 8) rsum[wave * 8 + lane] = csum;
     }
+    GNM_MSTAMP(2)
     __syncthreads();
     if (pro && p.p_gf && tid < 8) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -184,9 +237,8 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
 
     // ---- phase B ------------------------------------------------------------------------------
     const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
-    const bool need_deg = !p.backward && p.average;
+    const bool need_deg = AVG && !p.backward;
     const int col = col0 + i;
-    const float psc_i = pro ? p.p_scale[col] : 1.f, psh_i = pro ? p.p_shift[col] : 0.f;
     float lsc = 0.f, lsh = 0.f, lmu = 0.f, s_pb = 0.f, s_ub = 0.f;
     float ss1 = 0.f, ss2 = 0.f;
     if constexpr (STATS) {
@@ -197,36 +249,11 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         }
         if (p.s_dsc1) s_ub = p.s_U[(size_t)b * p.ld_U + col];
     }
-    const int role = (wave + cb) & 7;                           // rotate with the column block: evens out the SIMDs
-    const int rbA = role, rbB = role + 8;
-    const bool two = rbB < W;
-    const uint32_t* gbits = p.adj_bits + p.b_bits_off[b];
-    const unsigned bsel = h ? 0x07050301u : 0x06040200u;         // this half-wave's byte of every 16-bit step
-    const char* bp0 = smem + lane * 16;
+    const char* bp0 = smem + h * kAggmK8Stride + i * 16;
     const char* bp1 = bp0 + plane_bytes;
     const char* bp2 = bp1 + plane_bytes;
 
-    if (p.y && rbA < W) {
-        // this lane's bit rows (row rb * 32 + i), packed to the bytes its half-wave uses: byte m of pk[j] = step 4 j + m
-        unsigned pkA[7], pkB[7];
-        {
-            unsigned wa[14], wb[14];
-            const uint32_t* ra = gbits + (size_t)(rbA * 32 + i) * W;
-            const uint32_t* rb = gbits + (size_t)((two ? rbB : rbA) * 32 + i) * W;
-#pragma unroll
-            for (int d = 0; d < 14; ++d) {
-                wa[d] = d < W ? ra[d] : 0u;
-                wb[d] = d < W ? rb[d] : 0u;
-            }
-#pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                pkA[j] = __builtin_amdgcn_perm(wa[2 * j + 1], wa[2 * j], bsel);
-                pkB[j] = __builtin_amdgcn_perm(wb[2 * j + 1], wb[2 * j], bsel);
-            }
-        }
-        const int32_t* frp = p.rowptr + p.b_rp_off[b];
-        const bool shuffled = STATS && p.s_dsc1 && row0 < p.n_batch;   // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
-
+    if (has_rows) {
         f32x16 accA, accB;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
@@ -238,95 +265,153 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
             const u32x4 q = {l2.x, l2.y, h2.x, h2.y};
             return __builtin_bit_cast(bf16x8, q);
         };
+        auto bfrag = [&](const char* bp, int ks) -> bf16x8 {
+            return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + ks * kAggmStepBytes));
+        };
+        // The product, software-pipelined by hand: the operands of step ks + 1 are requested from LDS before the MFMAs
+        // of step ks are issued (left to the compiler, every step was  ds_read x5 -> wait -> 3 MFMA -> ds_read x2 -> wait
+        // -> 3 MFMA: two LDS round trips per 192 cycles of matrix work).  The MFMAs of the two row blocks alternate, so
+        // no MFMA waits for the one issued right before it.  Steps past the graph's last are skipped by a wave-uniform
+        // branch; what was requested for them is read from inside the workgroup's own LDS and dropped.
+        auto product = [&](auto two_tag) {
+            constexpr bool TWO = decltype(two_tag)::value;
+            bf16x8 b0 = bfrag(bp0, 0), b1 = bfrag(bp1, 0), b2 = bfrag(bp2, 0);
+            bf16x8 aA = afrag(pkA[0], 0), aB = aA;
+            if constexpr (TWO) aB = afrag(pkB[0], 0);
 #pragma unroll
-        for (int ks = 0; ks < 26; ++ks) {
-            if (ks < ksteps) {                                    // wave-uniform
-                const bf16x8 b0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp0 + ks * 1024));
-                const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp1 + ks * 1024));
-                const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp2 + ks * 1024));
-                const bf16x8 aA = afrag(pkA[ks >> 2], ks & 3);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b0, accA, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b1, accA, 0, 0, 0);
-                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b2, accA, 0, 0, 0);
-                if (two) {
-                    const bf16x8 aB = afrag(pkB[ks >> 2], ks & 3);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b0, accB, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b1, accB, 0, 0, 0);
-                    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b2, accB, 0, 0, 0);
-                }
-            }
-        }
-
-        // Epilogue on the accumulators (lane = column, 16 rows per lane), 8 rows at a time: the operands of 8 rows are
-        // requested together, behind the product (held across it, or for all 16 rows at once, they do not fit the
-        // 128 registers of 4 waves per SIMD; the other waves of the SIMD cover the wait).
-        auto epilogue = [&](int rb, const f32x16& acc) {
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {
-                float xs[8], zr[8], dv[8], dg[8], ex[8];
-                int vr[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = 8 * hb + q;
-                    vr[q] = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int vc = min(vr[q], n - 1);
-                    xs[q] = p.x[(size_t)(row0 + vc) * p.ldx + col];
-                    zr[q] = 0.f; dv[q] = 0.f; dg[q] = 1.f; ex[q] = 0.f;
-                    if constexpr (STATS) {
-                        zr[q] = p.sZ[(size_t)(row0 + vc) * p.ldsz + col];
-                        if (p.s_dsc1) dv[q] = p.s_dsc1[row0 + vc];
-                    }
-                    if (need_deg) dg[q] = (float)(frp[vc + 1] - frp[vc] + p.self_loop);
-                    else if (prescale && p.self_loop) dg[q] = (float)(drp[vc + 1] - drp[vc] + p.self_loop);
-                }
-                if constexpr (STATS) {
-                    if (shuffled) {                               // workgroup-uniform: the first B rows of the batch only
-                        int gq[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) gq[q] = p.s_inv_perm[min(row0 + min(vr[q], n - 1), p.n_batch - 1)];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const float t = p.s_s2sum[gq[q]] * p.s_U[(size_t)gq[q] * p.ld_U + col];
-                            ex[q] = row0 + min(vr[q], n - 1) < p.n_batch ? t : 0.f;
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int vrow = vr[q];
-                    float tot = acc[8 * hb + q];
-                    const float xv = xs[q];
-                    float wv = pro ? fmaxf(xv * psc_i + psh_i, 0.f) : xv;        // the tile's own value of this element
-                    if (p.self_loop) {
-                        if (prescale) wv = xv / dg[q];
-                        tot += wv;
-                    }
-                    if (need_deg) tot /= dg[q];                                  // 0/0 -> NaN as in the reference
-                    const float zrow = zr[q];
-                    if (!p.self_loop) {
-                        const float sb = prescale ? xv : wv;
-                        tot += selfB * sb;
-                        if constexpr (STATS) {
-                            if (p.deps_partial && !p.hfwd && vrow < n)
-                                dot += (double)(sb * fmaxf(zrow * lsc + lsh, 0.f));   // h recomputed as the forward formed it
-                        }
-                    }
-                    if constexpr (STATS) {
-                        tot += s_pb + dv[q] * s_ub;
-                        tot += ex[q];
-                        if (!(zrow * lsc + lsh > 0.f)) tot = 0.f;
-                        if (vrow < n) {
-                            ss1 += tot;
-                            ss2 += tot * (zrow - lmu);
-                        }
-                    }
-                    if (vrow < n) p.y[(size_t)(row0 + vrow) * p.ldy + col] = tot;
+            for (int ks = 0; ks < 26; ++ks) {
+                if (ks < ksteps) {                                // wave-uniform
+                    constexpr int LASTK = 25;
+                    const int kn = ks < LASTK ? ks + 1 : LASTK;
+                    const bf16x8 n0 = bfrag(bp0, kn), n1 = bfrag(bp1, kn), n2 = bfrag(bp2, kn);
+                    const bf16x8 nA = afrag(pkA[kn >> 2], kn & 3);
+                    bf16x8 nB = nA;
+                    if constexpr (TWO) nB = afrag(pkB[kn >> 2], kn & 3);
+                    __builtin_amdgcn_sched_barrier(0);            // the requests above stay above the MFMAs below
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b0, accA, 0, 0, 0);
+                    if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b0, accB, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b1, accA, 0, 0, 0);
+                    if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b1, accB, 0, 0, 0);
+                    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b2, accA, 0, 0, 0);
+                    if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b2, accB, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    b0 = n0; b1 = n1; b2 = n2; aA = nA; aB = nB;
                 }
             }
         };
-        epilogue(rbA, accA);
-        if (two) epilogue(rbB, accB);
+        // ---- epilogue on the accumulators: lane = column, 16 rows per lane, in half blocks of 8 rows ------------
+        // gfx950 retires vector-memory operations in issue order, stores included.  The first version asked for the
+        // next 8 rows' operands after storing the previous 8 and so paid an HBM write round trip per half block (the
+        // in-kernel timeline had the epilogues at 35-45 % of a workgroup's life -- even in the forward forms, which
+        // load nothing: a conditional load the launch does not take still leaves its vmcnt(0) behind).  Here nothing
+        // is conditional: rows past n are clipped by the store's buffer descriptor, an absent operand is loaded from
+        // a valid address and discarded, and the requests for half block k + 1 are issued BEFORE the stores of half
+        // block k, so the compiler's counted wait for them leaves those stores in flight.  The "sum" forward forms
+        // load nothing and wait for nothing.
+        const int32_t* frp = p.rowptr + p.b_rp_off[b];
+        const bool need_xs = prescale && !p.self_loop;      // the (1 + eps) self term of the "average" backward: raw input
+        const bool shuffled = STATS && p.s_dsc1 && row0 < p.n_batch;   // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
+        const bool has_dsc = STATS && p.s_dsc1 != nullptr;
+        const float* dscp = has_dsc ? p.s_dsc1 : p.x;       // absent: any readable address, value discarded
+        const bool want_dot = STATS && p.deps_partial && !p.hfwd && !p.self_loop;
+        const unsigned ybytes = (unsigned)(((size_t)(n - 1) * p.ldy + p.F) * 4);
+        const __amdgpu_buffer_rsrc_t ry =
+            __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)row0 * p.ldy, 0, (int)ybytes, 0x00020000);
+        // quarter blocks: 4 rows per lane at a time (r = 4 k + q: rows rb * 32 + 8 k + 4 h + q); two quarters' operands
+        // are in flight (with 8-row halves the two operand sets spilled at 128 registers)
+        struct Ops { float zr[4], dv[4], xs[4]; int d0[4], d1[4]; };
+        auto vrow_of = [&](int rb, int k, int q) { return rb * 32 + 8 * k + 4 * h + q; };
+        auto request = [&](int rb, int k, Ops& o) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int vc = min(vrow_of(rb, k, q), n - 1);
+                if constexpr (STATS) {
+                    o.zr[q] = p.sZ[(size_t)(row0 + vc) * p.ldsz + col];
+                    o.dv[q] = dscp[row0 + vc];
+                }
+                if constexpr (AVG) {
+                    o.xs[q] = p.x[(size_t)(row0 + vc) * p.ldx + col];
+                    o.d0[q] = frp[vc]; o.d1[q] = frp[vc + 1];
+                }
+            }
+        };
+        auto finish = [&](int rb, int k, const f32x16& acc, const Ops& o) {
+            float ex[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ex[q] = 0.f;
+            if constexpr (STATS) {
+                if (shuffled) {        // workgroup-uniform and rare (the workgroups of the first B rows of the batch)
+                    int gq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) gq[q] = p.s_inv_perm[min(row0 + min(vrow_of(rb, k, q), n - 1), p.n_batch - 1)];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float t = p.s_s2sum[gq[q]] * p.s_U[(size_t)gq[q] * p.ld_U + col];
+                        ex[q] = row0 + min(vrow_of(rb, k, q), n - 1) < p.n_batch ? t : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int vrow = vrow_of(rb, k, q);
+                float tot = acc[4 * k + q];
+                // the tile's own value of this element, as phase A formed it: the three planes add up to it exactly
+                const char* e = smem + (unsigned)(min(vrow, n16 - 1) >> 3) * kAggmK8Stride + i * 16 + (vrow & 7) * 2;
+                const float e1 = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(e) << 16);
+                const float e2 = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(e + plane_bytes) << 16);
+                const float e3 = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(e + 2u * plane_bytes) << 16);
+                const float wv = (e1 + e2) + e3;
+                if (p.self_loop) tot += wv;
+                if constexpr (AVG) {
+                    if (need_deg) tot /= (float)(o.d1[q] - o.d0[q] + p.self_loop);      // 0/0 -> NaN as in the reference
+                }
+                float sb = wv;
+                if constexpr (AVG) sb = need_xs ? o.xs[q] : wv;
+                if (!p.self_loop) tot += selfB * sb;
+                if constexpr (STATS) {
+                    const float zrow = o.zr[q];
+                    if (want_dot && vrow < n) dot += (double)(sb * fmaxf(zrow * lsc + lsh, 0.f));   // h as the forward formed it
+                    tot += s_pb + (has_dsc ? o.dv[q] : 0.f) * s_ub;
+                    tot += ex[q];
+                    if (!(zrow * lsc + lsh > 0.f)) tot = 0.f;
+                    if (vrow < n) {
+                        ss1 += tot;
+                        ss2 += tot * (zrow - lmu);
+                    }
+                }
+                // (row offset in the vector operand, scalar offset 0: see linear.hip, gnm_lin_stream_kernel)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ry, (vrow * p.ldy + col) * 4, 0, 0);
+            }
+        };
+        Ops oa, ob;
+        GNM_MSTAMP(3)
+        if (two) product(std::true_type{});
+        else product(std::false_type{});
+        GNM_MSTAMP(4)
+        request(rbA, 0, oa);       // (held across the product these registers spill at 4 waves per SIMD)
+        request(rbA, 1, ob);
+        finish(rbA, 0, accA, oa);
+        request(rbA, 2, oa);
+        finish(rbA, 1, accA, ob);
+        request(rbA, 3, ob);
+        finish(rbA, 2, accA, oa);
+        if (two) {
+            request(rbB, 0, oa);
+            finish(rbA, 3, accA, ob);
+            GNM_MSTAMP(5)
+            request(rbB, 1, ob);
+            finish(rbB, 0, accB, oa);
+            request(rbB, 2, oa);
+            finish(rbB, 1, accB, ob);
+            request(rbB, 3, ob);
+            finish(rbB, 2, accB, oa);
+            finish(rbB, 3, accB, ob);
+        } else {
+            finish(rbA, 3, accA, ob);
+            GNM_MSTAMP(5)
+        }
     }
+    GNM_MSTAMP(6)
 
     // ---- reductions (fixed order) ---------------------------------------------------------------
     if constexpr (STATS) {
@@ -363,12 +448,12 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
 }
 
 // ---- bit adjacency ----------------------------------------------------------------------------
-// graph g: W = ceil(n / 32) words per row, 32 W rows (zero rows pad the last 32-row block); bit (k % 32) of word
-// [v][k / 32] = 1 iff k is in row v of the CSR.  dup[g] = number of CSR entries that hit a bit already set (a
+// graph g: W = ceil(n / 32) words of bits per row, rows padded to WP = W rounded up to 4 words (16-byte rows), 32 W rows
+// (zero rows pad the last 32-row block); bit (k % 32) of word [v][k / 32] = 1 iff k is in row v of the CSR.  dup[g] = number of CSR entries that hit a bit already set (a
 // multigraph's repeated edge: the bit matrix cannot carry its weight -- the caller keeps such graphs on the CSR path).
 extern "C" long long gnm_adj_bits_words(int n) {
-    const long long W = (n + 31) / 32;
-    return W * 32 * W;
+    const long long W = (n + 31) / 32, WP = (W + 3) & ~3LL;
+    return W * 32 * WP;
 }
 extern "C" int gnm_aggm_max_nodes(void) { return kAggmMaxN; }
 extern "C" int gnm_aggm_num_partials(int F, int B) { return (F % 32) ? 0 : B * (F / 32); }
@@ -379,9 +464,9 @@ __global__ void __launch_bounds__(256) gnm_adj_bits_build_kernel(const int32_t* 
                                                                  const int64_t* g_bits_off, int32_t* dup) {
     const int g = blockIdx.x;
     const int n = g_n[g];
-    const int W = (n + 31) >> 5;
+    const int W = (n + 31) >> 5, WP = (W + 3) & ~3;
     uint32_t* out = bits + g_bits_off[g];
-    const int words = W * 32 * W;
+    const int words = W * 32 * WP;
     for (int k = threadIdx.x; k < words; k += blockDim.x) out[k] = 0u;
     __syncthreads();
     const int32_t* rp = rowptr + g_rp_off[g];
@@ -391,7 +476,7 @@ __global__ void __launch_bounds__(256) gnm_adj_bits_build_kernel(const int32_t* 
         for (int e = rp[v] + (threadIdx.x & 7); e < rp[v + 1]; e += 8) {
             const unsigned k = cl[e];
             const unsigned bit = 1u << (k & 31);
-            const unsigned old = atomicOr(out + (size_t)v * W + (k >> 5), bit);
+            const unsigned old = atomicOr(out + (size_t)v * WP + (k >> 5), bit);
             ndup += (old & bit) ? 1 : 0;
         }
     }
@@ -413,7 +498,7 @@ extern "C" int gnm_adj_bits_build(const int32_t* rowptr, const uint16_t* col, co
 
 // ---- launch -------------------------------------------------------------------------------------
 static bool aggm_shape_ok(const AggArgs& a, int n_max) {
-    if (!a.adj_bits || !a.b_bits_off) return false;
+    if (!a.adj_bits || !a.b_bits_off || (reinterpret_cast<uintptr_t>(a.adj_bits) & 15)) return false;
     if (n_max < 1 || n_max > kAggmMaxN) return false;
     if ((a.F & 31) || a.F > 256) return false;
     if ((a.ldx & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15)) return false;
@@ -422,18 +507,26 @@ static bool aggm_shape_ok(const AggArgs& a, int n_max) {
 }
 
 static int launch_aggm(AggArgs a, int B, int n_max, bool stats, hipStream_t stream) {
+#ifdef GNM_AGG16_TUNING
+    a.stamps = g_aggm_stamps;
+#else
+    a.stamps = nullptr;
+#endif
     a.n_graphs = B;
     a.n16_max = ((n_max + 15) / 16) * 16;
-    const size_t lds = (size_t)3 * a.n16_max * 64 + kAggmScratch;
+    const size_t lds = (size_t)3 * (a.n16_max / 8) * kAggmK8Stride + kAggmScratch;
     const int nc = a.F / 32;
     const int grid = ((B + 7) / 8) * 8 * nc;
-    if (stats) {
-        GNM_ALLOW_FULL_LDS(&gnm_aggm_kernel<true>);
-        hipLaunchKernelGGL(gnm_aggm_kernel<true>, dim3(grid), dim3(kAggmThreads), lds, stream, a);
-    } else {
-        GNM_ALLOW_FULL_LDS(&gnm_aggm_kernel<false>);
-        hipLaunchKernelGGL(gnm_aggm_kernel<false>, dim3(grid), dim3(kAggmThreads), lds, stream, a);
-    }
+#define GNM_AGGM_LAUNCH(S_, A_)                                                                              \
+    do {                                                                                                     \
+        GNM_ALLOW_FULL_LDS((&gnm_aggm_kernel<S_, A_>));                                                      \
+        hipLaunchKernelGGL((gnm_aggm_kernel<S_, A_>), dim3(grid), dim3(kAggmThreads), lds, stream, a);       \
+    } while (0)
+    if (stats && a.average) GNM_AGGM_LAUNCH(true, true);
+    else if (stats) GNM_AGGM_LAUNCH(true, false);
+    else if (a.average) GNM_AGGM_LAUNCH(false, true);
+    else GNM_AGGM_LAUNCH(false, false);
+#undef GNM_AGGM_LAUNCH
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }

@@ -110,9 +110,10 @@ int gnm_sum_partials(const double* partial, int count, float* out, void* stream)
  * The same three operations over a BIT adjacency: y = A x as MFMA products of the 0/1 matrix with three bf16 planes
  * of x (x split by truncation, every product exact: fp32-faithful like the gather).  Pays when the graphs are dense
  * (the 400-node benchmark graphs are 30 % dense: ~3x the gather); the caller chooses per batch.
- * Bit matrix of one graph with n nodes: W = ceil(n / 32) words per row, 32 W rows (zero rows pad the last block),
- * bit (k % 32) of word [v][k / 32] = 1 iff k is a neighbour in row v of that graph's CSR: gnm_adj_bits_words(n)
- * words at adj_bits + b_bits_off[b].  Built on the device from the arena's CSR by gnm_adj_bits_build, which also
+ * Bit matrix of one graph with n nodes: W = ceil(n / 32) words of bits per row, stored with a row stride of WP = W
+ * rounded up to a multiple of 4 words (16-byte rows), 32 W rows (zero rows pad the last block); bit (k % 32) of word
+ * [v][k / 32] = 1 iff k is a neighbour in row v of that graph's CSR: gnm_adj_bits_words(n) = 32 W WP words at
+ * adj_bits + b_bits_off[b] (adj_bits 16-byte aligned, offsets multiples of 4 words).  Built on the device from the arena's CSR by gnm_adj_bits_build, which also
  * counts, per graph, CSR entries that repeat an edge (dup[g] > 0: a multigraph -- the bit matrix cannot carry the
  * multiplicity, keep that graph on gnm_agg).  Pass the bit matrix of the TRANSPOSED CSR for backward = 1.
  * All other arguments: exactly as in gnm_agg / gnm_agg_bwd_stats / gnm_agg_fwd_bnrelu (rowptr and the offsets are

@@ -38,12 +38,15 @@ def test_bit_adjacency_matches_the_csr():
             assert not ar.bits_ok[gid]
             continue
         W = (n + 31) // 32
-        assert lib.gnm_adj_bits_words(n) == W * 32 * W
+        WP = (W + 3) // 4 * 4
+        assert lib.gnm_adj_bits_words(n) == W * 32 * WP
         A = np.zeros((n, n), dtype=bool)
         e = g.edge_mat.numpy()
         A[e[0], e[1]] = True
         for off, M in ((ar.bits_off[gid], A), (ar.t_bits_off[gid], A.T)):
-            w = bits[off:off + W * 32 * W].reshape(32 * W, W)
+            w = bits[off:off + W * 32 * WP].reshape(32 * W, WP)
+            assert not w[:, W:].any()                                       # padding words stay zero
+            w = w[:, :W]
             got = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).astype(bool).reshape(32 * W, 32 * W)
             assert np.array_equal(got[:n, :n], M)
             assert not got[n:].any() and not got[:, n:].any()             # padding rows / bits stay zero
