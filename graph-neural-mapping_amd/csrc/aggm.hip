@@ -34,7 +34,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-static constexpr int kAggmThreads = 512;
+#ifndef GNM_AGGM_WAVES
+#define GNM_AGGM_WAVES 8
+#endif
+static constexpr int kAggmWaves = GNM_AGGM_WAVES;   // row blocks w and w + kAggmWaves per wave (13 blocks at n = 400)
+static constexpr int kAggmThreads = 64 * kAggmWaves;
 static constexpr int kAggmMaxN = 416;            // 13 row blocks; up to 400 nodes two workgroups share a CU's LDS
 static constexpr int kAggmScratch = 128 + 1024;  // nibble table + readout partials
 // plane layout: [k / 8][32 columns][8 consecutive k] bf16, 528 bytes per k-group (512 + 16 of padding: the 8-byte
@@ -47,7 +51,7 @@ static unsigned long long* g_aggm_stamps = nullptr;
 extern "C" void gnm_debug_set_aggm_stamps(void* p) { g_aggm_stamps = reinterpret_cast<unsigned long long*>(p); }
 #define GNM_MSTAMP(k)                                                                                         \
     if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
-        p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime();
+        p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime();   /* <= 8 waves */
 #else
 #define GNM_MSTAMP(k)
 #endif
@@ -97,8 +101,8 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     GNM_MSTAMP(0)
     // This wave's output row blocks and their adjacency bits: requested first, so they arrive under phase A (the
     // timeline of the first version showed every wave waiting ~20 % of the workgroup's life for them behind the barrier)
-    const int role = (wave + cb) & 7;                           // rotate with the column block: evens out the SIMDs
-    const int rbA = role, rbB = role + 8;
+    const int role = (wave + cb) % kAggmWaves;                  // rotate with the column block: evens out the SIMDs
+    const int rbA = role, rbB = role + kAggmWaves;
     const bool two = rbB < W;
     const bool has_rows = p.y && rbA < W;
     // (rows are padded to whole 16-byte pieces: four coalescing-friendly loads per row instead of 13 scattered ones,
@@ -136,7 +140,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     }
     double dot = 0.0;
     const int nitems = (n16 >> 2) * 8;
-    constexpr int UA = 2;                                         // 416 / 4 * 8 = 832 items <= 2 x 512
+    constexpr int UA = (832 + kAggmThreads - 1) / kAggmThreads;   // 416 / 4 * 8 = 832 items
     float4 v[UA][4];
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
@@ -384,11 +388,11 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
             }
         };
         Ops oa, ob;
+        request(rbA, 0, oa);       // the first quarter's operands travel under the product
         GNM_MSTAMP(3)
         if (two) product(std::true_type{});
         else product(std::false_type{});
         GNM_MSTAMP(4)
-        request(rbA, 0, oa);       // (held across the product these registers spill at 4 waves per SIMD)
         request(rbA, 1, ob);
         finish(rbA, 0, accA, oa);
         request(rbA, 2, oa);
