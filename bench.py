@@ -74,20 +74,22 @@ def file_sha256(path):
     return h.hexdigest()
 
 
-def measured_traffic(profile_json, kernel_source, variant):
+def measured_traffic(profile_json, csrc_dir, variant):
     """HBM bytes per 1024-graph launch of the aggregation kernel from the committed PMC summary -- but only while
-    that summary was taken on THIS kernel source (sha256 of csrc/agg.hip recorded by tools/pmc_agg_summary.py);
-    a stale file yields (None, reason): a number that silently stops describing the kernel is worse than none."""
+    that entry was taken on THIS kernel source (each entry records the csrc file its kernel lives in and that file's
+    sha256, tools/pmc_agg_summary.py); a stale entry yields (None, reason): a number that silently stops describing
+    the kernel is worse than none."""
     if not os.path.exists(profile_json):
         return None, "no PMC summary (%s)" % os.path.basename(profile_json)
-    tj = json.load(open(profile_json))
-    have = file_sha256(kernel_source)
-    if tj.get("agg_hip_sha256") != have:
-        return None, "stale: %s was measured on agg.hip %s, this is %s" % (
-            os.path.basename(profile_json), str(tj.get("agg_hip_sha256"))[:12], have[:12])
-    ent = tj.get(variant)
-    if not ent:
+    ent = json.load(open(profile_json)).get(variant)
+    if not isinstance(ent, dict):
         return None, "no '%s' entry in %s" % (variant, os.path.basename(profile_json))
+    src = ent.get("kernel_source")
+    if not src or "sha256" not in ent:
+        return None, "stale: the '%s' entry of %s predates per-entry source hashes" % (variant, os.path.basename(profile_json))
+    have = file_sha256(os.path.join(csrc_dir, src))
+    if ent["sha256"] != have:
+        return None, "stale: '%s' was measured on %s %s, this is %s" % (variant, src, ent["sha256"][:12], have[:12])
     return float(ent["hbm_bytes_per_launch"]), ent["source"]
 
 
@@ -390,9 +392,14 @@ def main():
                 fused = bool(meta.get("fused_bnrelu"))
                 bytes_launch = AGG_BYTES_PER_GRAPH_LAYER(n, E, H) * meta["B"]
                 ach = bytes_launch / (ms * 1e-3) / 1e9
-                # which kernel these launches were (csrc/agg.hip: the 64-wide tile kernel, else feature slices)
+                # which kernel these launches were: the matrix-core kernel over the bit adjacency (csrc/aggm.hip, dense
+                # batches), else csrc/agg.hip: the 64-wide tile kernel or feature slices
                 fs = int(core.lib.gnm_agg_slice_width(H, n))
-                if fs == 64 and H == 64:
+                if meta.get("mfma"):
+                    kname = "gnm_aggm_kernel (MFMA over the bit adjacency, forward, F=%d%s)" % (
+                        H, ", with fused BatchNorm+ReLU+readout prologue" if fused else "")
+                    variant = "mfma_fused_bnrelu" if fused else "mfma_plain"
+                elif fs == 64 and H == 64:
                     kname = "gnm_agg16_kernel (forward, F=64%s)" % (
                         ", with fused BatchNorm+ReLU+readout prologue" if fused else "")
                     variant = "fused_bnrelu" if fused else "plain"
@@ -405,7 +412,7 @@ def main():
                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_agg.sh), counted on a 1024-graph
                     # launch; one workgroup per graph and slice, so it is linear in the graph count
                     per1024, traffic_src = measured_traffic(os.path.join(ROOT, "profiles", "agg_traffic.json"),
-                                                            os.path.join(PKG, "csrc", "agg.hip"), variant)
+                                                            os.path.join(PKG, "csrc"), variant)
                     if per1024 is not None:
                         traffic = per1024 * meta["B"] / 1024.0
                 roof = {"bound": "hbm", "kernel": kname, "achieved": ach,
@@ -430,7 +437,7 @@ def main():
                 c, ms, meta = summ[key]
                 fl = 2.0 * meta["N"] * H * H
                 tf = fl / (ms * 1e-3) / 1e12
-                roof_mlp = {"bound": "mfma", "kernel": "gnm_lin_kernel<64,2> (Linear %dx%d fwd)" % (H, H),
+                roof_mlp = {"bound": "mfma", "kernel": "gnm_lin_stream_kernel<64,2> (Linear %dx%d fwd)" % (H, H),
                             "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                             "mean_launch_ms": ms, "launches_timed": c,
                             "hbm_GBs": (meta["N"] * H * 4 * 2) / (ms * 1e-3) / 1e9}

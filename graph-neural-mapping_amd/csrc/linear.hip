@@ -483,12 +483,18 @@ __global__ void __launch_bounds__(256) gnm_lin_stream_kernel(const LinArgs p) {
 
     // weight -> LDS as Wt[k][h].  torch layout W[h][k]: a lane takes 4 consecutive k of one h (16-B global read) and
     // consecutive lanes take consecutive h, so the four transposed LDS writes of a wave fall in consecutive banks.
+    // (a weight inside a flat parameter buffer need not be 16-byte aligned: four 4-byte loads then)
+    const bool w_vec = (p.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0;
+    auto load_w4 = [&](const float* src) -> float4 {
+        if (w_vec) return *reinterpret_cast<const float4*>(src);
+        return make_float4(src[0], src[1], src[2], src[3]);
+    };
     if (p.w_kmajor) {
 #pragma unroll
         for (int it = 0; it < (KC * O4) / 256; ++it) {
             const int idx = tid + 256 * it;
             const int k = idx / O4, h4 = idx - k * O4;
-            *reinterpret_cast<float4*>(Wt + k * HP + 4 * h4) = *reinterpret_cast<const float4*>(p.W + (size_t)k * p.ldw + 4 * h4);
+            *reinterpret_cast<float4*>(Wt + k * HP + 4 * h4) = load_w4(p.W + (size_t)k * p.ldw + 4 * h4);
         }
     } else {
         float4 w[(C4 * HP) / 256];
@@ -496,7 +502,7 @@ __global__ void __launch_bounds__(256) gnm_lin_stream_kernel(const LinArgs p) {
         for (int it = 0; it < (C4 * HP) / 256; ++it) {
             const int idx = tid + 256 * it;
             const int k4 = idx / HP, hh = idx - k4 * HP;
-            w[it] = *reinterpret_cast<const float4*>(p.W + (size_t)hh * p.ldw + 4 * k4);
+            w[it] = load_w4(p.W + (size_t)hh * p.ldw + 4 * k4);
         }
 #pragma unroll
         for (int it = 0; it < (C4 * HP) / 256; ++it) {
@@ -701,8 +707,7 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
         int rc = GNM_ERR_UNSUPPORTED;
         // one chunk per row and descriptors that fit 32-bit offsets: the streaming kernel
         const bool small_ld = (long long)ldx * 32 * 4 < (1LL << 31) && (long long)ldz * 32 * 4 < (1LL << 31);
-        const bool w_vec = (ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
-        if ((K == 32 || K == 64) && small_ld && w_vec && !lin_no_stream()) {
+        if ((K == 32 || K == 64) && small_ld && !lin_no_stream()) {
 #define GNM_LINS_CASE(KC_, HT_) if (K == KC_ && HT == HT_) rc = launch_lin_stream<KC_, HT_>(a, grid, s);
             GNM_LINS_CASE(32, 1) GNM_LINS_CASE(32, 2) GNM_LINS_CASE(32, 3) GNM_LINS_CASE(32, 4)
             GNM_LINS_CASE(64, 1) GNM_LINS_CASE(64, 2) GNM_LINS_CASE(64, 3) GNM_LINS_CASE(64, 4)

@@ -225,8 +225,10 @@ LIN_CASES = [(1000, 64, 64), (1000, 7, 64), (33, 64, 64), (1, 5, 32), (777, 128,
 
 
 @pytest.mark.parametrize("N,K,H", LIN_CASES)
-@pytest.mark.parametrize("pro", [False, True])
-def test_linear_forward_stats_and_grads(N, K, H, pro):
+@pytest.mark.parametrize("pro,w_off", [(False, 0), (True, 0), (True, 5)])
+def test_linear_forward_stats_and_grads(N, K, H, pro, w_off):
+    """w_off: the weight sits w_off floats into a larger buffer, as a parameter inside the flat buffer of
+    gnm/parallel.py does -- not 16-byte aligned (the streaming kernel then stages it with 4-byte loads)."""
     from gnm import core
     from gnm._cabi import lib
     rng = np.random.default_rng(N * 131 + K * 7 + H)
@@ -235,7 +237,11 @@ def test_linear_forward_stats_and_grads(N, K, H, pro):
     b = rng.standard_normal(H).astype(np.float32)
     sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
     sh = rng.standard_normal(K).astype(np.float32)
-    Xd, Wd, bd = (torch.from_numpy(a).to(DEV) for a in (X, W, b))
+    Xd, bd = (torch.from_numpy(a).to(DEV) for a in (X, b))
+    flat = torch.zeros(w_off + H * K, device=DEV)
+    Wd = flat[w_off:].view(H, K)
+    Wd.copy_(torch.from_numpy(W))
+    assert (Wd.data_ptr() % 16 == 0) == (w_off % 4 == 0)
     scd, shd = torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV)
     Z = torch.full((N, H), float("nan"), device=DEV)
     grid = lib.gnm_linear_grid(N)

@@ -4,8 +4,10 @@
   * the entry of profiles/agg_traffic.json that bench.py reads for `roofline.traffic`,
     stamped with the sha256 of the csrc/agg.hip the counters were taken on.
 
-usage: python tools/pmc_agg_summary.py <gpurun_out/pmc_agg_TAG> <variant> <kernel-name-substring> <out.md> [graphs]
-  variant: plain | fused_bnrelu | backward_stats | sliced_n1000_F128 ...
+usage: python tools/pmc_agg_summary.py <gpurun_out/pmc_agg_TAG> <variant> <kernel-name-substring> <out.md> [graphs] [source]
+  variant: plain | fused_bnrelu | backward_stats | sliced_n1000_F128 | mfma_plain | mfma_fused_bnrelu | mfma_backward_stats
+  source:  the csrc file the kernel lives in (default agg.hip; aggm.hip for the mfma_* variants) -- its sha256 is
+           recorded with the entry, and bench.py drops the entry once that file changes
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE in KB units (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports
 half of a wide coalesced read stream; WRITE_SIZE is exact for 16-B-per-lane stores), scaled to a 1024-graph launch.
 """
@@ -33,16 +35,17 @@ def medians(pmc_dir, kernel_sub):
 def main():
     pmc_dir, variant, ksub, out_md = sys.argv[1:5]
     graphs = int(sys.argv[5]) if len(sys.argv) > 5 else 1024
+    src_name = sys.argv[6] if len(sys.argv) > 6 else ("aggm.hip" if variant.startswith("mfma_") else "agg.hip")
     m, dur_us, cnt = medians(pmc_dir, ksub)
     if "FETCH_SIZE" not in m or "WRITE_SIZE" not in m:
         raise SystemExit("no FETCH_SIZE / WRITE_SIZE rows for kernel '%s' under %s" % (ksub, pmc_dir))
     fetch_b, write_b = m["FETCH_SIZE"] * 1024.0, m["WRITE_SIZE"] * 1024.0
     hbm = 2.0 * fetch_b + write_b
-    agg = os.path.join(ROOT, "graph-neural-mapping_amd", "csrc", "agg.hip")
+    agg = os.path.join(ROOT, "graph-neural-mapping_amd", "csrc", src_name)
     sha = hashlib.sha256(open(agg, "rb").read()).hexdigest()
     lines = ["# %s -- PMC counters, variant `%s`" % (ksub, variant), "",
              "Source: `%s` (separate `rocprofv3 --kernel-trace --pmc` passes, medians over the profiled launches; "
-             "%d graphs per launch; csrc/agg.hip sha256 %s)." % (os.path.relpath(pmc_dir, ROOT), graphs, sha[:16]), "",
+             "%d graphs per launch; csrc/%s sha256 %s)." % (os.path.relpath(pmc_dir, ROOT), graphs, src_name, sha[:16]), "",
              "| counter | per launch (median) | launches |", "|---|---|---|"]
     for k in sorted(m):
         lines.append("| %s | %.5g | %d |" % (k, m[k], cnt[k]))
@@ -58,11 +61,10 @@ def main():
     open(out_md, "w").write("\n".join(lines) + "\n")
     tj_path = os.path.join(ROOT, "profiles", "agg_traffic.json")
     tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-    if tj.get("agg_hip_sha256") != sha:          # a new kernel source invalidates every older entry
-        tj = {"note": tj.get("note", ""), "agg_hip_sha256": sha}
+    tj.pop("agg_hip_sha256", None)               # (round 1 kept one hash for the whole file)
     tj[variant] = {"hbm_bytes_per_launch": hbm * 1024.0 / graphs, "fetch_size_bytes_raw": fetch_b,
                    "write_size_bytes": write_b, "graphs_in_profiled_launch": graphs, "kernel": ksub,
-                   "source": os.path.relpath(out_md, ROOT)}
+                   "kernel_source": src_name, "sha256": sha, "source": os.path.relpath(out_md, ROOT)}
     json.dump(tj, open(tj_path, "w"), indent=1)
     print(open(out_md).read())
 
