@@ -421,11 +421,42 @@ def main():
                         "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": bytes_launch, "mean_launch_ms": ms, "launches_timed": c,
                         "graph_layers_per_s": meta["B"] / (ms * 1e-3)}
+                if traffic is not None:
+                    # where the kernel moves fewer bytes than the canonical count (16-bit ids, or the bit
+                    # adjacency of the matrix-core kernel), also quote the fraction of peak the MOVED bytes amount to
+                    roof["frac_of_peak_from_traffic"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 if fused:
                     # the timed launches also apply the previous layer's BatchNorm+ReLU, write that activation
                     # (4nF bytes per graph, not part of SURVEY 8(d)'s canonical aggregation bytes) and its readout
                     extra = 4.0 * n * H * meta["B"]
                     roof["frac_incl_fused_activation_write"] = (bytes_launch + extra) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if meta.get("mfma") and rank == 0:
+                    # BASELINE.json's north_star describes the aggregation as a CSR neighbour-sum; dense batches run the
+                    # matrix-core kernel instead.  The CSR gather kernel stays the general path:
+                    # time it on the same batch here (outside the timed region, plain forward form) so that both
+                    # fractions are on record.  GNM_DENSE_FILL=2 runs the whole step on it.
+                    bt0 = batches[0][0]
+                    xg = torch.randn(bt0.N, H, device=dev)
+                    yg = torch.empty_like(xg)
+                    was = bt0.dense
+                    bt0.dense = False
+                    try:
+                        spec0 = model._spec
+                        epsp = model.eps.data_ptr() + 4 if spec0.learn_eps else None
+                        for _ in range(3):
+                            core._agg(bt0, xg, yg, H, epsp, spec0, backward=False)
+                        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+                        for a_, b_ in evs:
+                            a_.record(); core._agg(bt0, xg, yg, H, epsp, spec0, backward=False); b_.record()
+                        torch.cuda.synchronize()
+                        ms_g = float(np.median([a_.elapsed_time(b_) for a_, b_ in evs]))
+                    finally:
+                        bt0.dense = was
+                    roof["csr_gather"] = {
+                        "kernel": "gnm_agg16_kernel (CSR gather from the LDS tile, plain forward, F=%d), same batch, "
+                                  "timed after the run" % H,
+                        "median_launch_ms": ms_g, "launches_timed": 20,
+                        "frac": bytes_launch / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 bkey = "agg_bwd_F%d" % H
                 bc = [k for k in summ if k == bkey or k.startswith(bkey + "|")]
                 if bc:          # the backward launches (same canonical bytes: g in, dh out, same ids)

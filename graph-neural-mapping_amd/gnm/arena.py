@@ -18,9 +18,11 @@ from ._cabi import GnmError, check, lib
 
 # A batch takes the matrix-core aggregation (csrc/aggm.hip: bit adjacency x bf16 planes) when every graph in it has
 # a bit matrix and the batch is at least this dense (edges / nodes^2): the product costs ~n^2 per graph whatever the
-# edge count, the gather ~edges.  Measured crossover on MI355X at n = 400: ~8 % (the benchmark graphs are 30 %).
+# edge count, the gather ~edges plus a fixed part.  Measured on MI355X (tools/bench_agg.py --density, B = 1024,
+# n = 400, F = 64, us per launch, gather / matrix-core): 4 % 89 / 82, 8 % 97 / 80, 12 % 111 / 84, 20 % 153 / 82, the
+# benchmark's 30 % 175 / 83 -- the product already wins at the sparsest point measured, which is the threshold.
 # Tuning knob, read once: GNM_DENSE_FILL (a value > 1 turns the matrix-core path off).
-DENSE_MIN_FILL = float(os.environ.get("GNM_DENSE_FILL", "0.08"))
+DENSE_MIN_FILL = float(os.environ.get("GNM_DENSE_FILL", "0.04"))
 
 
 class _Growable:

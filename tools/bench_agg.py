@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--modes", default="plain,fused,bwdstats")
     ap.add_argument("--cold", action="store_true")
+    ap.add_argument("--density", type=float, default=None,
+                    help="random symmetric graphs of --nodes nodes with this edge density instead of the benchmark's "
+                         "dense-FC graphs (where does the gather beat the matrix-core kernel?)")
+    ap.add_argument("--nodes", type=int, default=400)
     ap.add_argument("--tag", default=os.environ.get("GNM_HIP_LIB", "product"))
     ap.add_argument("--check", action="store_true", help="spot-check the result against a dense fp64 product")
     ap.add_argument("--ab", default=None,
@@ -39,14 +43,22 @@ def main():
                          "launch i of every build before launch i + 1 of any -- clock drift and neighbours hit all alike")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    pool = synth.make_pool("dense_fc", args.pool)
+    if args.density is None:
+        pool = synth.make_pool("dense_fc", args.pool)
+    else:
+        rng0 = np.random.default_rng(1)
+        pool = []
+        for _ in range(min(args.pool, 64)):
+            src, dst = np.nonzero(np.triu(rng0.random((args.nodes, args.nodes)) < args.density, 1))
+            pool.append(synth.SynthGraph(args.nodes, np.stack([src, dst], 1), np.zeros((args.nodes, 7), np.float32), 0))
+        pool = [pool[k % len(pool)] for k in range(args.pool)]
     ar = GraphArena(dev)
     gids = np.array(ar.add_many(pool), dtype=np.int64)
     rng = np.random.default_rng(0)
     sel = rng.permutation(args.pool)[:args.batch] if args.pool >= args.batch else rng.integers(0, args.pool, args.batch)
     batch = ar.batch_from_gids(gids[sel])
     N, F, B = batch.N, args.F, batch.B
-    E = int(pool[0].edge_mat.shape[1])
+    E = int(np.mean([int(g.edge_mat.shape[1]) for g in pool[:64]]))
     x = torch.randn(N, F, device=dev)
     h = torch.randn(N, F, device=dev)
     y = torch.empty(N, F, device=dev)

@@ -2,12 +2,9 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-echo "== kernel tests"; timeout -k 10 900 python -m pytest tests/test_gpu_kernels.py -x -q > gpurun_out/r02j_pytest.log 2>&1; rc=$?; tail -3 gpurun_out/r02j_pytest.log; [ $rc -ne 0 ] && exit $rc
-echo "== bench"; timeout -k 10 600 python bench.py --steps 20 --warmup 5 --time-all-kernels --no-cpu-baseline > gpurun_out/r02j_bench.log 2>&1; tail -1 gpurun_out/r02j_bench.log | python3 -c "
-import json,sys
-j=json.loads(sys.stdin.read())
-print(round(j['value']), j['ms_per_step'], 'host', j['host_enqueue_ms_per_step'])
-for k,(c,ms) in sorted(j['kernel_ms'].items(), key=lambda kv:-kv[1][0]*kv[1][1]):
-    print('  %-40s %4d x %.4f ms = %.3f ms/step' % (k, c, ms, c*ms/20))
-print(j['roofline_mlp'])
-"
+for d in 0.04 0.08 0.12 0.16 0.20; do
+  echo "== density $d"; timeout -k 10 300 python tools/bench_agg.py --density $d --modes plain,mplain,bwdstats,mbwdstats --iters 20 2>&1 | grep AGG | cut -c1-100 | tee -a gpurun_out/r02j_density.log
+done
+for n in 100 200; do
+  echo "== n=$n density 0.3"; timeout -k 10 300 python tools/bench_agg.py --density 0.3 --nodes $n --modes plain,mplain --iters 20 2>&1 | grep AGG | cut -c1-100 | tee -a gpurun_out/r02j_density.log
+done
