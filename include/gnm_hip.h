@@ -21,9 +21,10 @@
  *   rowptr / col      per-graph CSR arena: int32 row offsets (n_g + 1 per graph,
  *                     graph-local, starting at 0) and uint16 graph-local column ids;
  *   b_rp_off[b]       offset (elements) of batch graph b's rowptr block in `rowptr`;
- *   b_col_off[b]      offset of its column block in `col`; `col` must stay readable for
- *                     128 ids past the end of the last block (the gather prefetches ids
- *                     unconditionally and discards those beyond a row's end);
+ *   b_col_off[b]      offset of its column block in `col`; `col` must be 4-byte aligned and stay
+ *                     readable for 256 ids past the end of the last block (the gather requests
+ *                     two 128-id windows per row as aligned id pairs, unconditionally, and
+ *                     discards what lies beyond the row's end);
  *   node_off[B+1]     first node row of each batch graph in the concatenated [N, F]
  *                     feature matrix (cumsum of len(graph.g), graphcnn.py:88-90).
  */
