@@ -160,8 +160,11 @@ def main():
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
                     help="c2: 400-node dense-FC graphs, hidden 64 (headline); c4: 1000-node kNN k=20, hidden 128")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the step from a captured hipGraph (auto: when --gpus > 1, where the host launch "
-                         "cost would otherwise bound the step; the N=1 run stays eager so per-kernel HIP events exist)")
+                    help="replay the step from a captured hipGraph.  auto: N > 1 replays every timed step (whichever of "
+                         "replay / eager is faster with the job's collective); N = 1 replays too, except every 4th timed "
+                         "step, which is launched eagerly so that HIP events can bracket the roofline kernels INSIDE the "
+                         "timed region.  An all-eager step costs ~2 ms of host time against ~3 ms of GPU time: on a box "
+                         "whose host is busy it is host-bound (4.1 ms measured once), replay is not.  off: all eager")
     ap.add_argument("--neighbor-pooling", default="sum", choices=["sum", "average"])
     ap.add_argument("--graph-pooling", default="sum", choices=["sum", "average"])
     ap.add_argument("--keep-pct", type=float, default=30.0,
@@ -263,7 +266,9 @@ def main():
         def loss_fn(c_logit, d_logit, lab):        # the same two losses, one fused pass (gnm_loss_ce_bce)
             return infomax_loss(c_logit, d_logit, lab, 0.05)[0]
 
-    use_graph = (args.graph == "on" or (args.graph == "auto" and world > 1)) and not args.sync_bn
+    use_graph = args.graph in ("on", "auto") and not args.sync_bn
+    # N = 1, auto: replayed steps with an eager step (HIP events on the roofline kernels) every `timer_every`
+    hybrid = args.graph == "auto" and world == 1 and not args.no_kernel_timer
     captured = None
     if use_graph:
         from gnm.graphs import CapturedTrainStep
@@ -281,9 +286,9 @@ def main():
     def feats(bt):          # explicit X = aggregate it in the step; None = arena cache (--agg0-cache)
         return None if args.agg0_cache else arena.features(bt)
 
-    def step(i):
+    def step(i, eager=False):
         bt, lab = batches[i]
-        if use_captured:
+        if use_captured and not eager:
             loss = captured.run(bt, lab, perms[i])
         else:
             dp.zero_grad()
@@ -316,7 +321,7 @@ def main():
     if not use_captured:
         captured = None
     kernel_timer = None
-    if not args.no_kernel_timer and captured is None:
+    if not args.no_kernel_timer and (captured is None or hybrid):
         kernel_timer = core.KernelTimer(None if args.time_all_kernels else
                                         ("agg_fwd_F%d" % H, "agg_bwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
     # the HIP events of the roofline kernels cost ~2 % of a step when recorded on every launch: they are recorded on
@@ -328,7 +333,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, nsteps):
         core.TIMER = kernel_timer if (i - args.warmup) % timer_every == 0 else None
-        loss = step(i)
+        loss = step(i, eager=core.TIMER is not None)
     core.TIMER = kernel_timer
     t_enqueued = time.perf_counter() - t0        # host time to enqueue all steps (no sync inside)
     torch.cuda.synchronize()
@@ -375,7 +380,9 @@ def main():
                        "pool_graphs_per_gpu": pool_n, "parallelism": "dp%d" % world},
             "final_loss": loss_val, "setup_seconds": round(t_gen, 1),
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
-            "launch_mode": "hipGraph replay" if captured is not None else "eager",
+            "launch_mode": ("eager" if captured is None else
+                            "hipGraph replay, every %d%s timed step eager with HIP events on the roofline kernels"
+                            % (timer_every, "th" if timer_every > 3 else "") if hybrid else "hipGraph replay"),
         }
         roof, roof_mlp = None, None
         default_cfg = (args.neighbor_pooling, args.graph_pooling, args.keep_pct, args.no_learn_eps) == \
@@ -425,9 +432,10 @@ def main():
                     # where the kernel moves fewer bytes than the canonical count (16-bit ids, or the bit
                     # adjacency of the matrix-core kernel), also quote the fraction of peak the MOVED bytes amount to
                     roof["frac_of_peak_from_traffic"] = traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-                if fused:
+                if fused and getattr(model._spec, "keep_hidden", False):
                     # the timed launches also apply the previous layer's BatchNorm+ReLU, write that activation
                     # (4nF bytes per graph, not part of SURVEY 8(d)'s canonical aggregation bytes) and its readout
+                    # (only when the arrays are kept: by default the activation is not written at all)
                     extra = 4.0 * n * H * meta["B"]
                     roof["frac_incl_fused_activation_write"] = (bytes_launch + extra) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 if meta.get("mfma") and rank == 0:

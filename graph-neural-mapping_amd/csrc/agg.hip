@@ -949,7 +949,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         auto emit = [&](int i, float4 w) {
             w.x = fmaxf(w.x * psc.x + psh.x, 0.f); w.y = fmaxf(w.y * psc.y + psh.y, 0.f);
             w.z = fmaxf(w.z * psc.z + psh.z, 0.f); w.w = fmaxf(w.w * psc.w + psh.w, 0.f);
-            *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + (i >> 4)) * p.p_ldh + 4 * (i & 15)) = w;
+            if (p.p_hout) *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + (i >> 4)) * p.p_ldh + 4 * (i & 15)) = w;
             csum.x += w.x; csum.y += w.y; csum.z += w.z; csum.w += w.w;
             tile[i] = w;
         };
@@ -1423,7 +1423,8 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
 // graph of the batch; 0 when even the narrowest slice does not fit in LDS.
 extern "C" int gnm_agg_slice_width(int F, int n_max) {
     int fs = 8;
-    while (fs < F && fs < 128) fs <<= 1;
+    static const int env_cap = gnm_env_int("GNM_AGG_SLICE_MAX", 128);   // tuning knob: widest slice tried
+    while (fs < F && fs < 128 && fs < env_cap) fs <<= 1;
     while (fs >= 8 && (size_t)(n_max + 1) * fs * 4 + (size_t)(n_max + 2) * 4 + 16 > (size_t)kLdsBudget - 1024) fs >>= 1;
     return fs >= 8 ? fs : 0;
 }
@@ -1512,11 +1513,11 @@ extern "C" int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, co
                                   int ldh, float* gf, int ldgf, int graph_avg, float* y, int ldy, int F,
                                   const float* eps, int average, int self_loop, void* stream) {
     if (B <= 0) return GNM_OK;
-    if (F != 64 || gnm_agg_slice_width(F, n_max) != 64 || !y || !z || !scale || !shift || !hout)
+    if (F != 64 || gnm_agg_slice_width(F, n_max) != 64 || !y || !z || !scale || !shift)
         return GNM_ERR_UNSUPPORTED;
     if ((size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 32 + (size_t)1024 * 16 > (size_t)kLdsBudget - 1024)
         return GNM_ERR_UNSUPPORTED;
-    if ((ldz & 3) || (ldh & 3) || (ldy & 3) || (gf && (ldgf & 3))) return GNM_ERR_UNSUPPORTED;
+    if ((ldz & 3) || (hout && (ldh & 3)) || (ldy & 3) || (gf && (ldgf & 3))) return GNM_ERR_UNSUPPORTED;
     const uintptr_t al = reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(scale) |
                          reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(hout) |
                          reinterpret_cast<uintptr_t>(gf) | reinterpret_cast<uintptr_t>(y);

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                     if (pro) {
                         w.x = fmaxf(w.x * psc.x + psh.x, 0.f); w.y = fmaxf(w.y * psc.y + psh.y, 0.f);
                         w.z = fmaxf(w.z * psc.z + psh.z, 0.f); w.w = fmaxf(w.w * psc.w + psh.w, 0.f);
-                        *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + row) * p.p_ldh + col0 + 4 * c4) = w;
+                        if (p.p_hout) *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + row) * p.p_ldh + col0 + 4 * c4) = w;
                         csum.x += w.x; csum.y += w.y; csum.z += w.z; csum.w += w.w;
                     }
                     if (prescale) {
@@ -597,8 +597,8 @@ extern "C" int gnm_aggm_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, c
                                    int graph_avg, float* y, int ldy, int F, const float* eps, int average,
                                    int self_loop, void* stream) {
     if (B <= 0) return GNM_OK;
-    if (F != 64 || !y || !z || !scale || !shift || !hout) return GNM_ERR_UNSUPPORTED;
-    if ((ldh & 3) || (gf && (ldgf & 3))) return GNM_ERR_UNSUPPORTED;
+    if (F != 64 || !y || !z || !scale || !shift) return GNM_ERR_UNSUPPORTED;
+    if ((hout && (ldh & 3)) || (gf && (ldgf & 3))) return GNM_ERR_UNSUPPORTED;
     const uintptr_t al = reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
                          reinterpret_cast<uintptr_t>(hout) | reinterpret_cast<uintptr_t>(gf);
     if (al & 15) return GNM_ERR_UNSUPPORTED;

@@ -12,9 +12,18 @@
 #include "gnm_common.h"
 
 #define GNM_MAX_LAYERS 16
+// Layer l of n_f is either given as the activation itself (sc[l] == null: p[l] = h_l) or, so that the activation
+// never has to be written to HBM, as the pre-BatchNorm output Z_l of the layer's last Linear with the folded
+// BatchNorm vectors: h_l = relu(Z_l * sc[l] + sh[l]) is then re-formed on the fly (graphcnn.py:163-166).
 struct HPtrs {
     const float* p[GNM_MAX_LAYERS];
+    const float* sc[GNM_MAX_LAYERS];
+    const float* sh[GNM_MAX_LAYERS];
 };
+__device__ __forceinline__ float4 gnm_bnrelu4(float4 x, float4 s, float4 h) {
+    return make_float4(fmaxf(x.x * s.x + h.x, 0.f), fmaxf(x.y * s.y + h.y, 0.f), fmaxf(x.z * s.z + h.z, 0.f),
+                       fmaxf(x.w * s.w + h.w, 0.f));
+}
 
 // d_logit[v] = sc_1[v], d_logit[N + v] = sc_2[g(v)]; one workgroup per graph.
 // A row of layer l is covered by H/4 lanes with 16-B loads (G = 64/(H/4) rows per
@@ -29,21 +38,34 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
                                                              float* __restrict__ d_logit) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Us = reinterpret_cast<float*>(smem);        // [L*H]
-    float* sc2s = Us + L * H;                          // [1]
+    float* Ss = Us + L * H;                            // [L*H] BatchNorm scale / shift of the layers given as Z
+    float* Sh = Ss + L * H;
+    float* sc2s = Sh + L * H;                          // [1]
     const int g = blockIdx.x;
     const int row0 = node_off[g];
     const int n = node_off[g + 1] - row0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;      // 256 threads, or 1024 for batches of few graphs
-    for (int e = tid; e < L * H; e += nthreads) Us[e] = U[(size_t)g * ldu + e];
+    unsigned tmask = 0;                                // layers given as Z (workgroup-uniform)
+    for (int l = 0; l < L; ++l) tmask |= hp.sc[l] ? 1u << l : 0u;
+    for (int e = tid; e < L * H; e += nthreads) {
+        Us[e] = U[(size_t)g * ldu + e];
+        const int l = e / H, c = e - l * H;
+        Ss[e] = hp.sc[l] ? hp.sc[l][c] : 1.f;
+        Sh[e] = hp.sc[l] ? hp.sh[l][c] : 0.f;
+    }
     __syncthreads();
     const float bv = bias ? bias[0] : 0.f;
     if (wave == 0) {
         const int pr = perm_rows[g];
         float a = 0.f;
         for (int l = 0; l < L; ++l)
-            for (int c = lane; c < H; c += 64) a += hp.p[l][(size_t)pr * ldh + c] * Us[l * H + c];
+            for (int c = lane; c < H; c += 64) {
+                float x = hp.p[l][(size_t)pr * ldh + c];
+                if (tmask >> l & 1) x = fmaxf(x * Ss[l * H + c] + Sh[l * H + c], 0.f);
+                a += x * Us[l * H + c];
+            }
         a = wave_sum(a);
         if (lane == 0) sc2s[0] = a + bv;
     }
@@ -68,9 +90,17 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
                 if (l < L) xx[l] = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);
 #pragma unroll
             for (int l = 0; l < ML; ++l)
-                if (l < L) a += xx[l].x * uu[l].x + xx[l].y * uu[l].y + xx[l].z * uu[l].z + xx[l].w * uu[l].w;
+                if (l < L) {
+                    if (tmask >> l & 1)
+                        xx[l] = gnm_bnrelu4(xx[l], *reinterpret_cast<const float4*>(Ss + l * H + 4 * sub),
+                                            *reinterpret_cast<const float4*>(Sh + l * H + 4 * sub));
+                    a += xx[l].x * uu[l].x + xx[l].y * uu[l].y + xx[l].z * uu[l].z + xx[l].w * uu[l].w;
+                }
             for (int l = ML; l < L; ++l) {
-                const float4 x = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);
+                float4 x = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);
+                if (tmask >> l & 1)
+                    x = gnm_bnrelu4(x, *reinterpret_cast<const float4*>(Ss + l * H + 4 * sub),
+                                    *reinterpret_cast<const float4*>(Sh + l * H + 4 * sub));
                 const float4 u = *reinterpret_cast<const float4*>(Us + l * H + 4 * sub);
                 a += x.x * u.x + x.y * u.y + x.z * u.z + x.w * u.w;
             }
@@ -86,7 +116,11 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
             const int v = row0 + r;
             float a = 0.f;
             for (int l = 0; l < L; ++l)
-                for (int c = lane; c < H; c += 64) a += hp.p[l][(size_t)v * ldh + c] * Us[l * H + c];
+                for (int c = lane; c < H; c += 64) {
+                    float x = hp.p[l][(size_t)v * ldh + c];
+                    if (tmask >> l & 1) x = fmaxf(x * Ss[l * H + c] + Sh[l * H + c], 0.f);
+                    a += x * Us[l * H + c];
+                }
             a = wave_sum(a);
             if (lane == 0) {
                 d_logit[v] = a + bv;
@@ -96,14 +130,25 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
     }
 }
 
-extern "C" int gnm_disc_score_fwd(const float* const* hptrs, int ldh, int L, int H, const float* U, int ldu,
+static void fill_hptrs(HPtrs& hp, const float* const* hptrs, const float* const* scale_ptrs,
+                       const float* const* shift_ptrs, int L) {
+    for (int l = 0; l < GNM_MAX_LAYERS; ++l) {
+        hp.p[l] = l < L ? hptrs[l] : nullptr;
+        const bool z = l < L && scale_ptrs && shift_ptrs && scale_ptrs[l] && shift_ptrs[l];
+        hp.sc[l] = z ? scale_ptrs[l] : nullptr;
+        hp.sh[l] = z ? shift_ptrs[l] : nullptr;
+    }
+}
+
+extern "C" int gnm_disc_score_fwd(const float* const* hptrs, const float* const* scale_ptrs,
+                                  const float* const* shift_ptrs, int ldh, int L, int H, const float* U, int ldu,
                                   const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
                                   float* d_logit, void* stream) {
     if (B <= 0) return GNM_OK;
     if (L <= 0 || L > GNM_MAX_LAYERS || H <= 0) return GNM_ERR_BAD_ARG;
     HPtrs hp;
-    for (int l = 0; l < GNM_MAX_LAYERS; ++l) hp.p[l] = l < L ? hptrs[l] : nullptr;
-    const size_t lds = (size_t)(L * H + 4) * 4;
+    fill_hptrs(hp, hptrs, scale_ptrs, shift_ptrs, L);
+    const size_t lds = (size_t)(3 * L * H + 4) * 4;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool vec = ((ldh & 3) == 0) && ((H & 3) == 0);
     const int lpr4 = vec ? H / 4 : 0;
@@ -168,6 +213,12 @@ __global__ void __launch_bounds__(1024) gnm_disc_du_kernel(const HPtrs hp, int l
     const int pr = perm_rows[g];
     for (int l = 0; l < L; ++l) {
         const float* hl = hp.p[l];
+        const bool asz = hp.sc[l] != nullptr;               // this layer is given as Z + folded BatchNorm
+        float4 lsc = make_float4(1.f, 1.f, 1.f, 1.f), lsh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (asz && c4 < H4) {
+            lsc = *reinterpret_cast<const float4*>(hp.sc[l] + 4 * c4);
+            lsh = *reinterpret_cast<const float4*>(hp.sh[l] + 4 * c4);
+        }
         if (rg < RP) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int r = rg;
@@ -182,13 +233,15 @@ __global__ void __launch_bounds__(1024) gnm_disc_du_kernel(const HPtrs hp, int l
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
+                    if (asz) x[u] = gnm_bnrelu4(x[u], lsc, lsh);
                     acc.x += w[u] * x[u].x; acc.y += w[u] * x[u].y; acc.z += w[u] * x[u].z; acc.w += w[u] * x[u].w;
                 }
             }
             for (; r < n; r += RP) {
                 const int v = row0 + r;
                 const float w = dD[v];
-                const float4 x = *reinterpret_cast<const float4*>(hl + (size_t)v * ldh + 4 * c4);
+                float4 x = *reinterpret_cast<const float4*>(hl + (size_t)v * ldh + 4 * c4);
+                if (asz) x = gnm_bnrelu4(x, lsc, lsh);
                 acc.x += w * x.x; acc.y += w * x.y; acc.z += w * x.z; acc.w += w * x.w;
             }
             red[rg * H4 + c4] = acc;
@@ -200,7 +253,9 @@ __global__ void __launch_bounds__(1024) gnm_disc_du_kernel(const HPtrs hp, int l
                 const float4 x = red[q * H4 + tid];
                 t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
             }
-            const float4 x = *reinterpret_cast<const float4*>(hl + (size_t)pr * ldh + 4 * tid);
+            float4 x = *reinterpret_cast<const float4*>(hl + (size_t)pr * ldh + 4 * tid);
+            if (asz) x = gnm_bnrelu4(x, *reinterpret_cast<const float4*>(hp.sc[l] + 4 * tid),
+                                     *reinterpret_cast<const float4*>(hp.sh[l] + 4 * tid));
             t.x += s2 * x.x; t.y += s2 * x.y; t.z += s2 * x.z; t.w += s2 * x.w;
             *reinterpret_cast<float4*>(dU + (size_t)g * ldu + (size_t)l * H + 4 * tid) = t;
         }
@@ -208,14 +263,15 @@ __global__ void __launch_bounds__(1024) gnm_disc_du_kernel(const HPtrs hp, int l
     }
 }
 
-extern "C" int gnm_disc_score_bwd(const float* const* hptrs, int ldh, int L, int H, const float* dD,
+extern "C" int gnm_disc_score_bwd(const float* const* hptrs, const float* const* scale_ptrs,
+                                  const float* const* shift_ptrs, int ldh, int L, int H, const float* dD,
                                   const int32_t* perm_rows, const int32_t* node_off, int N, int B, float* dU, int ldu,
                                   float* s2sum, float* dsum, int32_t* inv_perm, void* stream) {
     if (B <= 0) return GNM_OK;
     if (L <= 0 || L > GNM_MAX_LAYERS || H <= 0 || (H & 3) || H > 1024 || (ldh & 3) || (ldu & 3))
         return GNM_ERR_BAD_ARG;
     HPtrs hp;
-    for (int l = 0; l < GNM_MAX_LAYERS; ++l) hp.p[l] = l < L ? hptrs[l] : nullptr;
+    fill_hptrs(hp, hptrs, scale_ptrs, shift_ptrs, L);
     const int threads = B >= 1024 ? 256 : 1024;       // one workgroup per graph: few graphs -> big workgroups
     const int H4 = H >> 2, RP = threads / H4;
     hipLaunchKernelGGL(gnm_disc_du_kernel, dim3(B), dim3(threads), (size_t)RP * H4 * 16,

@@ -155,6 +155,10 @@ class GinSpec:
         # the data-parallel group) and global_count(n).  When set, train-mode BatchNorm normalises with the
         # statistics of the UNION batch, so W ranks reproduce one process on the whole batch.  Eager launches only.
         self.sync_bn = None
+        # True: every layer's activation h_l = relu(bn(z_l)) is written to memory as an array (test hooks that read
+        # them).  Default: layers whose BatchNorm + ReLU ride on the next aggregation's tile load exist only as ZAct
+        # (z, scale, shift) -- the discriminator re-forms them in its kernels; 105 MB per layer less HBM traffic.
+        self.keep_hidden = False
 
 
 def _dense(batch, F_):
@@ -260,8 +264,10 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
             pooled = torch.empty((N, F_l), **f32)
             fused = False
             if pending is not None:
-                # the previous layer's BatchNorm + ReLU + readout ride on this aggregation's tile load
+                # the previous layer's BatchNorm + ReLU + readout ride on this aggregation's tile load; unless the
+                # caller wants the arrays (spec.keep_hidden) the activation itself is not written
                 z, scale, shift, hout, gslice = pending
+                hout_ptr, hout_ld = (hout.data_ptr(), hout.stride(0)) if hout is not None else (None, 0)
                 rc = -2
                 if _dense(batch, F_l):
                     with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1, mfma=1) as tm:
@@ -269,7 +275,7 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
                             a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
                             batch.col_off.data_ptr(), a.bits.buf.data_ptr(), batch.bits_off.data_ptr(),
                             batch.node_off.data_ptr(), B, batch.n_max, z.data_ptr(), z.stride(0), scale.data_ptr(),
-                            shift.data_ptr(), hout.data_ptr(), hout.stride(0), gslice.data_ptr(), g_f.stride(0),
+                            shift.data_ptr(), hout_ptr, hout_ld, gslice.data_ptr(), g_f.stride(0),
                             int(spec.g_avg), pooled.data_ptr(), pooled.stride(0), F_l, eps_ptr, int(spec.n_avg),
                             int(not spec.learn_eps), _stream())
                         if rc != 0:
@@ -279,19 +285,23 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
                         rc = lib.gnm_agg_fwd_bnrelu(
                             a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
                             batch.col_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max,
-                            z.data_ptr(), z.stride(0), scale.data_ptr(), shift.data_ptr(), hout.data_ptr(),
-                            hout.stride(0), gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), pooled.data_ptr(),
+                            z.data_ptr(), z.stride(0), scale.data_ptr(), shift.data_ptr(), hout_ptr,
+                            hout_ld, gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), pooled.data_ptr(),
                             pooled.stride(0), F_l, eps_ptr, int(spec.n_avg), int(not spec.learn_eps), _stream())
                         if rc != 0:
                             tm.cancel()       # declined (or failed): no launch happened, the fallback below times itself
                 if rc == -2:
-                    readout(*pending)
+                    if hout is None:                 # declined: the unfused pair of kernels needs the array after all
+                        hout = torch.empty((N, z.shape[1]), **f32)
+                        hidden[-1] = hout
+                        h = hout
+                    readout(z, scale, shift, hout, gslice)
                 else:
                     check(rc, "gnm_agg_fwd_bnrelu")
                     fused = True
                 pending = None
             if not fused:
-                _agg(batch, h, pooled, F_l, eps_ptr, spec, backward=False)    # graphcnn.py:154-161 / 178-182
+                _agg(batch, hidden_tensor(h), pooled, F_l, eps_ptr, spec, backward=False)    # graphcnn.py:154-161 / 178-182
         x_in, pro, lins = pooled, None, []
         for k in range(m):                                                   # mlp.py:40-49
             if m == 1:
@@ -320,21 +330,70 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
                                       sv.mean.data_ptr(), sv.rstd.data_ptr(), _stream()), "gnm_bn_finalize")
             lins.append(sv)
             x_in, pro = z, (sv.scale, sv.shift)
-        hout = torch.empty((N, H), **f32)
         gslice = g_f[:, l * H:(l + 1) * H]
         if l < L - 1:
-            pending = (x_in, pro[0], pro[1], hout, gslice)      # deferred into the next layer's aggregation
+            # deferred into the next layer's aggregation, which (on its fused path) does not write the activation
+            hout = torch.empty((N, H), **f32) if getattr(spec, "keep_hidden", False) else None
+            pending = (x_in, pro[0], pro[1], hout, gslice)
+            hnew = hout if hout is not None else ZAct(x_in, pro[0], pro[1])
         else:
+            hout = torch.empty((N, H), **f32)
             readout(x_in, pro[0], pro[1], hout, gslice)
+            hnew = hout
         saved.append((h, pooled, lins))
-        hidden.append(hout)
-        h = hout
+        hidden.append(hnew)
+        h = hnew
     return hidden, g_f, saved
+
+
+class ZAct:
+    """A layer output that is not in memory: h = relu(z * scale + shift) (graphcnn.py:163-166) with z the pre-BatchNorm
+    output of the layer's last Linear and (scale, shift) its folded BatchNorm.  Its BatchNorm + ReLU ran on the tile
+    load of the next layer's aggregation, which did not write it (105 MB per layer at the
+    headline shape); the only other consumer, the discriminator, re-forms it in its kernels from the same three
+    tensors.  tensor() materialises it for the rare paths that want the array (unfused fallbacks, test hooks)."""
+    __slots__ = ("z", "scale", "shift", "_h")
+
+    def __init__(self, z, scale, shift):
+        self.z, self.scale, self.shift, self._h = z, scale, shift, None
+
+    @property
+    def shape(self):
+        return self.z.shape
+
+    def tensor(self):
+        if self._h is None:
+            self._h = torch.relu(torch.addcmul(self.shift, self.z, self.scale))
+        return self._h
+
+
+def hidden_tensor(h):
+    """the [N, H] array of a layer output, whichever way encoder_forward holds it"""
+    return h.tensor() if isinstance(h, ZAct) else h
 
 
 def _hptr_array(hidden):
     arr = (C.c_void_p * len(hidden))(*[t.data_ptr() for t in hidden])
     return arr
+
+
+def _hidden_ptr_arrays(hidden):
+    """(pointers, scale pointers, shift pointers, leading dimension) for gnm_disc_score_fwd / _bwd: a ZAct layer is
+    passed as its z with the BatchNorm vectors, a materialised one as itself (NULL vectors)"""
+    n = len(hidden)
+    hp, sp, tp = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    ld = None
+    for l, h in enumerate(hidden):
+        if isinstance(h, ZAct):
+            hp[l], sp[l], tp[l] = h.z.data_ptr(), h.scale.data_ptr(), h.shift.data_ptr()
+            stride = h.z.stride(0)
+        else:
+            hp[l], sp[l], tp[l] = h.data_ptr(), None, None
+            stride = h.stride(0)
+        if ld is not None and stride != ld:
+            raise GnmError("hidden layers with different leading dimensions (%d, %d)" % (ld, stride))
+        ld = stride
+    return hp, sp, tp, ld
 
 
 _ptr_array = _hptr_array
@@ -407,7 +466,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                 # idles while the host catches up
                 perm_rows = torch.as_tensor(perm, dtype=torch.int32).pin_memory().to(X.device, non_blocking=True)
             d_logit = torch.empty((2 * N, 1), dtype=torch.float32, device=X.device)
-            check(lib.gnm_disc_score_fwd(_hptr_array(hidden), hidden[0].stride(0), L, H, U.data_ptr(), U.stride(0),
+            hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
+            check(lib.gnm_disc_score_fwd(hp_, sp_, tp_, ldh_, L, H, U.data_ptr(), U.stride(0),
                                          perm_rows.data_ptr(), P["disc.f_k.bias"].data_ptr(),
                                          batch.node_off.data_ptr(), N, B, d_logit.data_ptr(), _stream()),
                   "gnm_disc_score_fwd")
@@ -461,7 +521,8 @@ class GinInfoMaxFn(torch.autograd.Function):
             s2sum = torch.empty(B, **f32)
             dsum = torch.empty(B, **f32)
             inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
-            check(lib.gnm_disc_score_bwd(_hptr_array(hidden), hidden[0].stride(0), L, H, dD.data_ptr(),
+            hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
+            check(lib.gnm_disc_score_bwd(hp_, sp_, tp_, ldh_, L, H, dD.data_ptr(),
                                          ctx.perm_rows.data_ptr(), batch.node_off.data_ptr(), N, B, dU.data_ptr(),
                                          dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(), inv_perm.data_ptr(), st),
                   "gnm_disc_score_bwd")
@@ -528,7 +589,7 @@ class GinInfoMaxFn(torch.autograd.Function):
         dX = None
         pre_outer = None
         for l in reversed(range(L)):
-            h_in, pooled, lins = saved[l]
+            h_in, pooled, lins = saved[l]            # h_in: this layer's input (X, an array, or a ZAct)
             F_l = h_in.shape[1]
             incoming = dH_next                       # grad wrt this layer's output from the layer above
             # (G, partial, nblk) when the producer of this gradient already applied the ReLU mask and reduced
@@ -691,12 +752,13 @@ class GinInfoMaxFn(torch.autograd.Function):
                     # nothing below consumes d h: only d eps[l] = sum dpooled . h is needed -- a flat dot product
                     eps_counts[l] = int(lib.gnm_rowdot_num_partials())
                     with _timed("deps_dot_F%d" % F_l, N=N, F=F_l):
-                        check(lib.gnm_rowdot_partials(dpooled.data_ptr(), dpooled.stride(0), h_in.data_ptr(),
-                                                      h_in.stride(0), N, F_l, part.data_ptr(), st),
+                        hin_t = hidden_tensor(h_in)
+                        check(lib.gnm_rowdot_partials(dpooled.data_ptr(), dpooled.stride(0), hin_t.data_ptr(),
+                                                      hin_t.stride(0), N, F_l, part.data_ptr(), st),
                               "gnm_rowdot_partials")
                 elif not fused:
                     cnt = _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True,
-                               hfwd=h_in if spec.learn_eps else None, deps_partial=part)
+                               hfwd=hidden_tensor(h_in) if spec.learn_eps else None, deps_partial=part)
                     if spec.learn_eps:
                         eps_counts[l] = cnt
                 if l > 0:

@@ -95,7 +95,9 @@ int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t*
                       const int32_t* inv_perm, const float* s2sum, double* s_partial, void* stream);
 /* gnm_agg of layer l+1 whose tile load IS layer l's outer BatchNorm + ReLU + graph readout
  * (graphcnn.py:163-166 and :229 folded into :154-161): z = output of layer l's last Linear, hout <- h_l =
- * relu(z*scale+shift), gf[b,:] <- sum (mean when graph_avg) of h_l over graph b (gf may be NULL), y <- the
+ * relu(z*scale+shift) (hout may be NULL: the activation is then not written -- its other consumer, the
+ * discriminator, can re-form it from z, see gnm_disc_score_fwd), gf[b,:] <- sum (mean when graph_avg) of h_l over
+ * graph b (gf may be NULL), y <- the
  * aggregation of h_l.  64-wide single-slice shape only: GNM_ERR_UNSUPPORTED otherwise (then gnm_bn_relu_readout
  * followed by gnm_agg). */
 int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
@@ -219,15 +221,20 @@ int gnm_bn_bwd_apply(const float* G, int ldg, const float* Z, int ldz, const flo
 
 /* ---- Infomax discriminator (discriminator.py:19-38, graphcnn.py:233-246) ------------
  * hptrs_host: HOST array of L device pointers to the per-layer [N,H] hidden states
- * (n_f is never concatenated).  U = sigmoid(g_f) W^T, [B, L*H].  perm_rows[g] =
- * perm[g], the ROW of n_f the reference's shuffle index selects for graph g.
- * d_logit: [2N] (= the reference's [2N,1]). */
-int gnm_disc_score_fwd(const float* const* hptrs_host, int ldh, int L, int H, const float* U, int ldu,
+ * (n_f is never concatenated).  A layer may instead be given as the pre-BatchNorm output Z_l of its last Linear
+ * plus the folded BatchNorm vectors: scale_ptrs_host[l] / shift_ptrs_host[l] non-NULL (HOST arrays of L device
+ * pointers to [H] vectors, or NULL arrays) make the kernels use relu(hptrs[l] * scale + shift) (graphcnn.py:163-166),
+ * so the activation never has to exist in memory (gnm_agg_fwd_bnrelu with hout = NULL).
+ * U = sigmoid(g_f) W^T, [B, L*H].  perm_rows[g] = perm[g], the ROW of n_f the reference's shuffle index selects
+ * for graph g.  d_logit: [2N] (= the reference's [2N,1]). */
+int gnm_disc_score_fwd(const float* const* hptrs_host, const float* const* scale_ptrs_host,
+                       const float* const* shift_ptrs_host, int ldh, int L, int H, const float* U, int ldu,
                        const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
                        float* d_logit, void* stream);
 /* optional by-products: dsum[g] = sum over graph g of dD (both halves; their total is d bias), and
  * inv_perm[perm_rows[g]] = g. */
-int gnm_disc_score_bwd(const float* const* hptrs_host, int ldh, int L, int H, const float* dD,
+int gnm_disc_score_bwd(const float* const* hptrs_host, const float* const* scale_ptrs_host,
+                       const float* const* shift_ptrs_host, int ldh, int L, int H, const float* dD,
                        const int32_t* perm_rows, const int32_t* node_off, int N, int B, float* dU, int ldu,
                        float* s2sum, float* dsum, int32_t* inv_perm, void* stream);
 

@@ -451,14 +451,21 @@ def test_batchnorm_relu_readout_forward_backward(sizes, H, training, average):
     assert_close(dbet.cpu().numpy(), db_ref, rtol=TOL, what="dbeta", floor=floor)
 
 
-@pytest.mark.parametrize("B,n,L,H", [(3, 24, 5, 64), (4, 20, 3, 32), (2, 1, 2, 64), (5, 400, 5, 64)])
-def test_discriminator_scores_vs_literal_bilinear(B, n, L, H):
+@pytest.mark.parametrize("B,n,L,H", [(3, 24, 5, 64), (4, 20, 3, 32), (2, 1, 2, 64), (5, 400, 5, 64), (3, 17, 3, 20)])
+@pytest.mark.parametrize("as_z", [False, True])
+def test_discriminator_scores_vs_literal_bilinear(B, n, L, H, as_z):
     """gnm_disc_score_fwd/_bwd vs the literal nn.Bilinear formulation of discriminator.py:19-38
-    (oracle restatement), including the graph-index-as-row-index shuffle quirk."""
+    (oracle restatement), including the graph-index-as-row-index shuffle quirk.
+    as_z: all layers but the last are handed over as the pre-BatchNorm Z with folded (scale, shift), the way the model
+    does when the activation is never written; the kernels re-form h = relu(Z * scale + shift) (graphcnn.py:163-166)."""
     from gnm._cabi import check, lib
     rng = np.random.default_rng(B * 100 + n)
     N, LH = B * n, L * H
-    hs = [rng.standard_normal((N, H)).astype(np.float32) for _ in range(L)]
+    zs = [rng.standard_normal((N, H)).astype(np.float32) for _ in range(L)]
+    scs = [rng.uniform(0.5, 1.5, H).astype(np.float32) for _ in range(L)]
+    shs = [(rng.standard_normal(H) * 0.3).astype(np.float32) for _ in range(L)]
+    given_as_z = [as_z and l < L - 1 for l in range(L)]
+    hs = [np.maximum(zs[l] * scs[l] + shs[l], np.float32(0)) if given_as_z[l] else zs[l] for l in range(L)]
     n_f = np.concatenate(hs, 1).astype(np.float64)
     c = rng.uniform(0, 1, (B, LH)).astype(np.float32)
     Wd = (rng.standard_normal((LH, LH)) / LH).astype(np.float32)
@@ -469,14 +476,17 @@ def test_discriminator_scores_vs_literal_bilinear(B, n, L, H):
     sc1 = ((n_f @ Wd.astype(np.float64)) * c_x).sum(1) + bias
     sc2 = ((n_f[idx] @ Wd.astype(np.float64)) * c_x).sum(1) + bias
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
-    hd = [t(h) for h in hs]
+    hd = [t(z) for z in zs]                                   # arrays as handed to the kernels: Z or h per layer
+    scd, shd = [t(a) for a in scs], [t(a) for a in shs]
     U = t((c.astype(np.float64) @ Wd.astype(np.float64).T).astype(np.float32))
     node_off = t(np.arange(B + 1, dtype=np.int32) * n)
     perm_rows = t(perm.astype(np.int32))
     d_logit = torch.empty(2 * N, device=DEV)
     hp = (C.c_void_p * L)(*[h.data_ptr() for h in hd])
+    sp = (C.c_void_p * L)(*[scd[l].data_ptr() if given_as_z[l] else None for l in range(L)]) if as_z else None
+    tp = (C.c_void_p * L)(*[shd[l].data_ptr() if given_as_z[l] else None for l in range(L)]) if as_z else None
     bd = t(np.array([bias]))
-    check(lib.gnm_disc_score_fwd(hp, H, L, H, U.data_ptr(), LH, perm_rows.data_ptr(), bd.data_ptr(),
+    check(lib.gnm_disc_score_fwd(hp, sp, tp, H, L, H, U.data_ptr(), LH, perm_rows.data_ptr(), bd.data_ptr(),
                                  node_off.data_ptr(), N, B, d_logit.data_ptr(), _stream()), "disc fwd")
     assert_close(d_logit.cpu().numpy(), np.concatenate([sc1, sc2]), rtol=TOL, what="d_logit")
     # backward wrt U and the negative-branch sums
@@ -486,7 +496,7 @@ def test_discriminator_scores_vs_literal_bilinear(B, n, L, H):
     dDd = t(dD)
     dsum = torch.empty(B, device=DEV)
     inv_perm = torch.full((B,), -1, dtype=torch.int32, device=DEV)
-    check(lib.gnm_disc_score_bwd(hp, H, L, H, dDd.data_ptr(), perm_rows.data_ptr(), node_off.data_ptr(), N, B,
+    check(lib.gnm_disc_score_bwd(hp, sp, tp, H, L, H, dDd.data_ptr(), perm_rows.data_ptr(), node_off.data_ptr(), N, B,
                                  dU.data_ptr(), LH, s2.data_ptr(), dsum.data_ptr(), inv_perm.data_ptr(), _stream()),
           "disc bwd")
     d1, d2 = dD[:N].astype(np.float64), dD[N:].astype(np.float64)

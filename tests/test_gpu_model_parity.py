@@ -86,7 +86,8 @@ def capture_layers(model):
 
     def wrapped(*a, **k):
         hidden, g_f, saved = orig(*a, **k)
-        store["hidden"] = [h.detach().cpu().numpy() for h in hidden]
+        # (layers that exist only as (z, scale, shift) -- core.ZAct -- are materialised the way their consumers re-form them)
+        store["hidden"] = [core.hidden_tensor(h).detach().cpu().numpy() for h in hidden]
         store["pooled"] = [s[1].detach().cpu().numpy() for s in saved]
         return hidden, g_f, saved
 

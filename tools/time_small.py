@@ -32,6 +32,6 @@ def t(f, n=20):
     for _ in range(n): f()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
-print("disc_score_fwd us", t(lambda: check(lib.gnm_disc_score_fwd(hp, H, L, H, U.data_ptr(), L * H, perm.data_ptr(), bias.data_ptr(), bt.node_off.data_ptr(), N, B, d.data_ptr(), st), "f")))
+print("disc_score_fwd us", t(lambda: check(lib.gnm_disc_score_fwd(hp, None, None, H, L, H, U.data_ptr(), L * H, perm.data_ptr(), bias.data_ptr(), bt.node_off.data_ptr(), N, B, d.data_ptr(), st), "f")))
 dU = torch.empty_like(U); s2 = torch.empty(B, device=dev)
-print("disc_score_bwd us", t(lambda: check(lib.gnm_disc_score_bwd(hp, H, L, H, d.data_ptr(), perm.data_ptr(), bt.node_off.data_ptr(), N, B, dU.data_ptr(), L * H, s2.data_ptr(), None, None, st), "b")))
+print("disc_score_bwd us", t(lambda: check(lib.gnm_disc_score_bwd(hp, None, None, H, L, H, d.data_ptr(), perm.data_ptr(), bt.node_off.data_ptr(), N, B, dU.data_ptr(), L * H, s2.data_ptr(), None, None, st), "b")))
