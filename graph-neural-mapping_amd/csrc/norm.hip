@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(1024) gnm_bn_relu_readout_kernel(
             if (relu) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            *reinterpret_cast<float4*>(Hout + (size_t)(row0 + r) * ldh + 4 * c4) = v;
+            if (Hout) *reinterpret_cast<float4*>(Hout + (size_t)(row0 + r) * ldh + 4 * c4) = v;   // (kernel-uniform)
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
         red[rg * H4 + c4] = acc;
@@ -155,7 +155,8 @@ extern "C" int gnm_bn_relu_readout(const float* Z, int ldz, const float* scale, 
                                    int ldh, const int32_t* node_off, int B, int H, int relu, float* pooled, int ldp,
                                    int average, void* stream) {
     if (B <= 0) return GNM_OK;
-    if (H <= 0 || (H & 3) || H > 1024 || (ldz & 3) || (ldh & 3) || (pooled && (ldp & 3))) return GNM_ERR_BAD_ARG;
+    if (H <= 0 || (H & 3) || H > 1024 || (ldz & 3) || (Hout && (ldh & 3)) || (pooled && (ldp & 3))) return GNM_ERR_BAD_ARG;
+    if (!Hout && !pooled) return GNM_OK;             // nothing to produce
     // one workgroup per graph: with fewer graphs than ~4 per CU, 256-thread workgroups leave the chip idle
     const int threads = per_graph_threads(B);
     const int H4 = H >> 2, RP = threads / H4;

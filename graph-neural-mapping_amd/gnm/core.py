@@ -250,7 +250,8 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
 
     def readout(z, scale, shift, hout, gslice):
         check(lib.gnm_bn_relu_readout(z.data_ptr(), z.stride(0), scale.data_ptr(), shift.data_ptr(),
-                                      hout.data_ptr(), hout.stride(0), batch.node_off.data_ptr(), B, H, 1,
+                                      ptr(hout), hout.stride(0) if hout is not None else 0,
+                                      batch.node_off.data_ptr(), B, H, 1,
                                       gslice.data_ptr(), g_f.stride(0), int(spec.g_avg), _stream()),
               "gnm_bn_relu_readout")                                          # graphcnn.py:163-166, 228-229
 
@@ -337,9 +338,10 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
             pending = (x_in, pro[0], pro[1], hout, gslice)
             hnew = hout if hout is not None else ZAct(x_in, pro[0], pro[1])
         else:
-            hout = torch.empty((N, H), **f32)
+            # the top layer: only its readout is needed now; the discriminator re-forms the activation like the others
+            hout = torch.empty((N, H), **f32) if getattr(spec, "keep_hidden", False) else None
             readout(x_in, pro[0], pro[1], hout, gslice)
-            hnew = hout
+            hnew = hout if hout is not None else ZAct(x_in, pro[0], pro[1])
         saved.append((h, pooled, lins))
         hidden.append(hnew)
         h = hnew

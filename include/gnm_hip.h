@@ -200,7 +200,8 @@ int gnm_bn_finalize(const double* stats_partial, int nblk, int H, long long nrow
                     const float* beta, float* running_mean, float* running_var, long long* num_batches_tracked,
                     float momentum, float eps, int training, int update_running, float* scale, float* shift,
                     float* mean_out, float* rstd_out, void* stream);
-/* Hout = relu(Z*scale+shift); pooled[b] = sum (or mean) of graph b's rows (may be null). */
+/* Hout = relu(Z*scale+shift) (may be null: only the readout is wanted); pooled[b] = sum (or mean) of graph b's
+ * rows (may be null). */
 int gnm_bn_relu_readout(const float* Z, int ldz, const float* scale, const float* shift, float* Hout, int ldh,
                         const int32_t* node_off, int B, int H, int relu, float* pooled, int ldp, int average,
                         void* stream);
