@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--modes", default="plain,fused,bwdstats")
     ap.add_argument("--cold", action="store_true")
+    ap.add_argument("--keep-hidden", action="store_true",
+                    help="fused forms: also write the activation h = relu(bn(z)) (the model does not, by default)")
     ap.add_argument("--density", type=float, default=None,
                     help="random symmetric graphs of --nodes nodes with this edge density instead of the benchmark's "
                          "dense-FC graphs (where does the gather beat the matrix-core kernel?)")
@@ -112,8 +114,8 @@ def main():
             core.check(lib.gnm_aggm_fwd_bnrelu(
                 a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
                 a.bits.buf.data_ptr(), batch.bits_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max,
-                x.data_ptr(), F, sc.data_ptr(), sh.data_ptr(), h.data_ptr(), F, gf.data_ptr(), F, 0, y.data_ptr(), F, F,
-                eps.data_ptr(), 0, 0, st), "gnm_aggm_fwd_bnrelu")
+                x.data_ptr(), F, sc.data_ptr(), sh.data_ptr(), h.data_ptr() if args.keep_hidden else None, F, gf.data_ptr(),
+                F, 0, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, st), "gnm_aggm_fwd_bnrelu")
             return
         if mode == "mbwdstats":
             core.check(lib.gnm_aggm_bwd_stats(
@@ -128,8 +130,8 @@ def main():
             core.check(lib.gnm_agg_fwd_bnrelu(
                 a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
                 batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, x.data_ptr(), F, sc.data_ptr(),
-                sh.data_ptr(), h.data_ptr(), F, gf.data_ptr(), F, 0, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, st),
-                "gnm_agg_fwd_bnrelu")
+                sh.data_ptr(), h.data_ptr() if args.keep_hidden else None, F, gf.data_ptr(), F, 0, y.data_ptr(), F, F,
+                eps.data_ptr(), 0, 0, st), "gnm_agg_fwd_bnrelu")
         elif mode == "bwd":
             core._agg(batch, x, y, F, eps.data_ptr(), spec, True, hfwd=h, deps_partial=part)
         elif mode == "bwdstats":
