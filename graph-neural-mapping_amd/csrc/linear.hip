@@ -22,6 +22,7 @@
 // tuning knobs, read once per process
 static bool lin_force_generic() { static const bool v = getenv("GNM_LIN_GENERIC") != nullptr; return v; }
 static bool lin_no_stream() { static const bool v = getenv("GNM_LIN_NO_STREAM") != nullptr; return v; }   // tuning: A/B
+static bool linbwd_no_pipe() { static const bool v = getenv("GNM_LINBWD_NO_PIPE") != nullptr; return v; }   // tuning: A/B
 static bool linbwd_no_samez() { static const bool v = getenv("GNM_LINBWD_NO_SAMEZ") != nullptr; return v; }
 
 struct LinArgs {
@@ -1421,6 +1422,244 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     GNM_LSTAMP(63)
 }
 
+// ---------------------------------------------------------------------------------
+// The same fused backward for the form that has no statistics to reduce (the FIRST Linear of an MLP: its input is
+// the aggregation output), software-pipelined across tiles: the G / Z tile of the wave's NEXT tile is requested in the
+// middle of the current one -- behind the dgrad MFMAs, when the A fragments' 32 registers are free -- and travels
+// under the wgrad MFMAs and the epilogue (the in-kernel timeline had a wave of the kernel above waiting for G and Z
+// for 30-38 % of its life).  gfx950 retires vector-memory operations in issue order, so for that wait to be a counted
+// one (not a drain that also waits for the dX stores issued after the request) every access between them is
+// unconditional: tile loads and dX stores go through buffer descriptors that clip rows past N, and the first tile is
+// peeled so that the loop is entered with the same queue its back edge carries (see gnm_lin_stream_kernel).
+// The statistics variants above stay as they are: at 256 registers they have no room for a tile in flight (tried:
+// 31-150 spills), and any restructuring of that kernel's body moved its register allocation.
+// ---------------------------------------------------------------------------------
+template <int KT, int HT>
+__global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArgs p) {
+    constexpr int KP = KT * 32, HP = HT * 32;
+    constexpr int XS = (KP > HP ? KP : HP) + 4;
+    constexpr int H4 = HP / 4;
+    constexpr int NLD = (32 * H4) / 64;
+    constexpr int RSTEP = 64 / H4;
+    constexpr int KH = HP / 2;
+    constexpr int O4 = KP / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Wt = reinterpret_cast<float*>(smem);                   // [HP][KP]
+    float* Xs_all = Wt + (size_t)HP * KP;                         // [4][32][XS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float* Xs = Xs_all + wave * 32 * XS;
+    for (int idx = tid; idx < HP * KP; idx += 256) {
+        const int hh = idx / KP, k = idx - hh * KP;
+        Wt[idx] = p.W[(size_t)hh * p.ldw + k];
+    }
+    const int c4 = lane % H4, lrow0 = lane / H4;
+    const float4 mu = *reinterpret_cast<const float4*>(p.mean + 4 * c4);
+    const float4 rs = *reinterpret_cast<const float4*>(p.rstd + 4 * c4);
+    const float4 ca = *reinterpret_cast<const float4*>(p.cA + 4 * c4);
+    const float4 a1 = *reinterpret_cast<const float4*>(p.m1 + 4 * c4);
+    const float4 a2 = *reinterpret_cast<const float4*>(p.m2 + 4 * c4);
+    float psc[KT], psh[KT];
+#pragma unroll
+    for (int b = 0; b < KT; ++b) {
+        psc[b] = p.pro_scale ? p.pro_scale[32 * b + i] : 1.f;
+        psh[b] = p.pro_scale ? p.pro_shift[32 * b + i] : 0.f;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): nothing from the preamble is pending inside the tile loop
+    __syncthreads();
+    f32x16 wacc[HT][KT];
+#pragma unroll
+    for (int a = 0; a < HT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wacc[a][b][r] = 0.f;
+    float dbacc[HT];
+#pragma unroll
+    for (int a = 0; a < HT; ++a) dbacc[a] = 0.f;
+
+    const int ntiles = (p.N + 31) / 32;
+    const int tstride = gridDim.x * 4;
+    const int gz_voff_g = (lrow0 * p.ldg + 4 * c4) * 4, gz_step_g = RSTEP * p.ldg * 4;
+    const int gz_voff_z = (lrow0 * p.ldz + 4 * c4) * 4, gz_step_z = RSTEP * p.ldz * 4;
+    const int x_voff = (h * p.ldx + i) * 4;                       // X[r0 + 2 s + h][32 b + i]
+    const int out_voff = ((lane / O4) * p.lda + 4 * (lane % O4)) * 4, out_step = (64 / O4) * p.lda * 4;
+    // (no dX wanted: an empty descriptor over any readable address -- the stores stay unconditional)
+    const float* dxbase = p.dA ? p.dA : p.G;
+
+    u32x4 g4[NLD], z4[NLD];
+    auto load_gz = [&](int tile) {
+        const long long row0 = (long long)tile * 32;
+        const long long rows = min((long long)p.N - row0, 32LL);
+        const __amdgpu_buffer_rsrc_t rg = gnm_tile_rsrc(p.G + row0 * p.ldg, rows, p.ldg, HP);
+        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + row0 * p.ldz, rows, p.ldz, HP);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            g4[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, gz_voff_g, j * gz_step_g, 0);
+            z4[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, gz_voff_z, j * gz_step_z, 0);
+        }
+    };
+    auto do_tile = [&](int t, int t_next) {
+        const int r0 = t * 32;
+        const int rows = min(p.N - r0, 32);
+        // ---- dZ tile -> LDS (rows past N are zero: they must not contribute) ----------
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int lrow = lrow0 + j * RSTEP;
+            const float4 gj = __builtin_bit_cast(float4, g4[j]), zj = __builtin_bit_cast(float4, z4[j]);
+            float4 d;
+            d.x = ca.x * (gj.x - a1.x - (zj.x - mu.x) * rs.x * a2.x);
+            d.y = ca.y * (gj.y - a1.y - (zj.y - mu.y) * rs.y * a2.y);
+            d.z = ca.z * (gj.z - a1.z - (zj.z - mu.z) * rs.z * a2.z);
+            d.w = ca.w * (gj.w - a1.w - (zj.w - mu.w) * rs.w * a2.w);
+            if (lrow >= rows) d = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4*>(Xs + lrow * XS + 4 * c4) = d;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // f(X) operands of the wgrad product: in flight during the dgrad MFMAs (clipped rows read 0; their dZ is 0)
+        float xv[16][KT];
+        {
+            const __amdgpu_buffer_rsrc_t rx = gnm_tile_rsrc(p.X + (size_t)r0 * p.ldx, rows, p.ldx, KP);
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int b = 0; b < KT; ++b)
+                    xv[s][b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, x_voff, (2 * s * p.ldx + 32 * b) * 4, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- dX = dZ W ------------------------------------------------------------------
+        f32x16 dacc[KT];
+        {
+            float a[KH];
+#pragma unroll
+            for (int j = 0; j < KH / 4; ++j) {
+                const float4 v = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 4 * j);
+                a[4 * j + 0] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+            }
+#pragma unroll
+            for (int c = 0; c < KT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[c][r] = 0.f;
+            const float* wrow = Wt + (size_t)(KH * h) * KP + i;
+#pragma unroll
+            for (int s = 0; s < KH; ++s) {
+#pragma unroll
+                for (int c = 0; c < KT; ++c)
+                    dacc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], wrow[s * KP + 32 * c], dacc[c], 0, 0, 0);
+            }
+        }
+        load_gz(t_next);                          // past the wave's last tile: empty descriptors, no traffic
+        // ---- dW += dZ^T f(X), db += column sums of dZ -----------------------------------
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            float av[HT];
+            const int krow = 2 * s + h;
+#pragma unroll
+            for (int a = 0; a < HT; ++a) av[a] = Xs[krow * XS + 32 * a + i];
+            float xf[KT];
+#pragma unroll
+            for (int b = 0; b < KT; ++b) {
+                float x = xv[s][b];
+                if (p.pro_scale) {
+                    x = x * psc[b] + psh[b];
+                    if (p.pro_relu) x = fmaxf(x, 0.f);
+                }
+                xf[b] = x;
+            }
+#pragma unroll
+            for (int a = 0; a < HT; ++a) {
+                dbacc[a] += av[a];
+#pragma unroll
+                for (int b = 0; b < KT; ++b)
+                    wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], xf[b], wacc[a][b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // everyone is done reading the dZ image
+        // ---- store dX through the staging image (16-B row-contiguous, clipped buffer stores) ---------
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Xs[((r & 3) + 8 * (r >> 2) + 4 * h) * XS + 32 * c + i] = dacc[c][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const __amdgpu_buffer_rsrc_t rd = gnm_tile_rsrc(dxbase + (p.dA ? (size_t)r0 * p.lda : 0), p.dA ? rows : 0, p.lda, KP);
+#pragma unroll
+            for (int st = 0; st < (32 * O4) / 64; ++st) {
+                const int idx = lane + 64 * st;
+                const int row = idx / O4, oc = idx - row * O4;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(Xs + row * XS + 4 * oc);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, out_voff + st * out_step, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    {
+        int t = blockIdx.x * 4 + wave;
+        load_gz(t);
+        if (t < ntiles) {
+            do_tile(t, t + tstride);                  // peeled
+            for (t += tstride; t < ntiles; t += tstride) do_tile(t, t + tstride);
+        }
+    }
+
+    // ---- combine the 4 waves' dW / db in a fixed order: one partial per block (as in the kernel above) ----
+    __syncthreads();
+    constexpr int TILE = 16 * 64;
+    float* dump = reinterpret_cast<float*>(smem);
+    float* mine = dump + (size_t)wave * HT * KT * TILE;
+#pragma unroll
+    for (int a = 0; a < HT; ++a)
+#pragma unroll
+        for (int b = 0; b < KT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(a * KT + b) * TILE + r * 64 + lane] = wacc[a][b][r];
+    float* dbdump = dump + (size_t)4 * HT * KT * TILE;
+#pragma unroll
+    for (int a = 0; a < HT; ++a) dbdump[(wave * HT + a) * 64 + lane] = dbacc[a];
+    __syncthreads();
+    float* out = p.partial + (size_t)blockIdx.x * ((size_t)p.H * p.K + p.H);
+    for (int idx = tid; idx < HT * KT * TILE; idx += 256) {
+        const int ab = idx / TILE;
+        const int rl = idx - ab * TILE;
+        const int r = rl >> 6, ln = rl & 63;
+        const int a = ab / KT, b = ab - a * KT;
+        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int col = 32 * b + (ln & 31);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += dump[(size_t)w * HT * KT * TILE + idx];
+        out[(size_t)row * p.K + col] = sum;
+    }
+    for (int idx = tid; idx < HT * 32; idx += 256) {
+        const int a = idx >> 5, ii = idx & 31;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += dbdump[(w * HT + a) * 64 + ii] + dbdump[(w * HT + a) * 64 + 32 + ii];
+        out[(size_t)p.H * p.K + 32 * a + ii] = sum;
+    }
+}
+
+template <int KT, int HT>
+static int launch_lb_pipe(const LbArgs& a, int grid, hipStream_t s) {
+    constexpr int KP = KT * 32, HP = HT * 32;
+    constexpr int XS = (KP > HP ? KP : HP) + 4;
+    size_t lds = (size_t)HP * KP * 4 + (size_t)4 * 32 * XS * 4;
+    const size_t dump = ((size_t)4 * HT * KT * 1024 + (size_t)4 * HT * 64) * 4;
+    if (dump > lds) lds = dump;
+    GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_pipe_kernel<KT, HT>));
+    hipLaunchKernelGGL((gnm_linear_bwd_pipe_kernel<KT, HT>), dim3(grid), dim3(256), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false>
 static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     constexpr int KP = KT * 32, HP = HT * 32;
@@ -1484,15 +1723,23 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     const int grid = gnm_linear_bwd_grid(N);
     int rc = GNM_ERR_UNSUPPORTED;
     const int KT = narrow ? 0 : K / 32, HT = H / 32;
+    // no statistics to reduce (the first Linear of an MLP): the cross-tile pipelined kernel
+    const bool pipe = !narrow && !sZ && !linbwd_no_pipe();
+    if (pipe) {
+        if (KT == 1 && HT == 1) rc = launch_lb_pipe<1, 1>(a, grid, s);
+        if (KT == 2 && HT == 1) rc = launch_lb_pipe<2, 1>(a, grid, s);
+        if (KT == 1 && HT == 2) rc = launch_lb_pipe<1, 2>(a, grid, s);
+        if (KT == 2 && HT == 2) rc = launch_lb_pipe<2, 2>(a, grid, s);
+    }
     if (narrow && HT == 1) rc = launch_lb<1, 1, false, true>(a, grid, s);
     if (narrow && HT == 2) rc = launch_lb<1, 2, false, true>(a, grid, s);
-    if (KT == 1 && HT == 1) rc = sZ ? launch_lb<1, 1, true>(a, grid, s) : launch_lb<1, 1, false>(a, grid, s);
-    if (KT == 2 && HT == 1) rc = sZ ? launch_lb<2, 1, true>(a, grid, s) : launch_lb<2, 1, false>(a, grid, s);
-    if (KT == 1 && HT == 2) rc = sZ ? launch_lb<1, 2, true>(a, grid, s) : launch_lb<1, 2, false>(a, grid, s);
+    if (!pipe && KT == 1 && HT == 1) rc = sZ ? launch_lb<1, 1, true>(a, grid, s) : launch_lb<1, 1, false>(a, grid, s);
+    if (!pipe && KT == 2 && HT == 1) rc = sZ ? launch_lb<2, 1, true>(a, grid, s) : launch_lb<2, 1, false>(a, grid, s);
+    if (!pipe && KT == 1 && HT == 2) rc = sZ ? launch_lb<1, 2, true>(a, grid, s) : launch_lb<1, 2, false>(a, grid, s);
     // the second Linear of an MLP: the lower BatchNorm's input is this Linear's input and its affine is the prologue
     const bool samez = sZ && sZ == X && ldsz == ldx && s_scale == pro_scale && s_shift == pro_shift && pro_relu &&
                        !linbwd_no_samez();
-    if (KT == 2 && HT == 2)
+    if (!pipe && KT == 2 && HT == 2)
         rc = samez ? launch_lb<2, 2, true, false, true>(a, grid, s)
                    : (sZ ? launch_lb<2, 2, true>(a, grid, s) : launch_lb<2, 2, false>(a, grid, s));
     if (rc != GNM_OK) return rc;
