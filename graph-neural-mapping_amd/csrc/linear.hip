@@ -1431,8 +1431,9 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
 // one (not a drain that also waits for the dX stores issued after the request) every access between them is
 // unconditional: tile loads and dX stores go through buffer descriptors that clip rows past N, and the first tile is
 // peeled so that the loop is entered with the same queue its back edge carries (see gnm_lin_stream_kernel).
-// The statistics variants above stay as they are: at 256 registers they have no room for a tile in flight (tried:
-// 31-150 spills), and any restructuring of that kernel's body moved its register allocation.
+// The statistics variants above stay as they are: at 256 registers they have no room for a tile in flight (tried, in
+// the shared template and as a SAMEZ flavour of this kernel with the request behind the wgrad MFMAs: 31-150 spills),
+// and any restructuring of that kernel's body moved its register allocation.
 // ---------------------------------------------------------------------------------
 template <int KT, int HT>
 __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArgs p) {
@@ -1446,6 +1447,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Wt = reinterpret_cast<float*>(smem);                   // [HP][KP]
     float* Xs_all = Wt + (size_t)HP * KP;                         // [4][32][XS]
+    float* coef = Xs_all + 4 * 32 * XS;                           // [5][HP]: mean, rstd, cA, m1, m2 of the BatchNorm
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1455,12 +1457,13 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
         const int hh = idx / KP, k = idx - hh * KP;
         Wt[idx] = p.W[(size_t)hh * p.ldw + k];
     }
+    // the BatchNorm-backward coefficient vectors live in LDS and are read per tile (5 ds_read_b128: they count on
+    // lgkmcnt, so re-reading them costs no place in the in-order vector-memory queue and no registers across the tile)
+    for (int idx = tid; idx < HP; idx += 256) {
+        coef[idx] = p.mean[idx]; coef[HP + idx] = p.rstd[idx]; coef[2 * HP + idx] = p.cA[idx];
+        coef[3 * HP + idx] = p.m1[idx]; coef[4 * HP + idx] = p.m2[idx];
+    }
     const int c4 = lane % H4, lrow0 = lane / H4;
-    const float4 mu = *reinterpret_cast<const float4*>(p.mean + 4 * c4);
-    const float4 rs = *reinterpret_cast<const float4*>(p.rstd + 4 * c4);
-    const float4 ca = *reinterpret_cast<const float4*>(p.cA + 4 * c4);
-    const float4 a1 = *reinterpret_cast<const float4*>(p.m1 + 4 * c4);
-    const float4 a2 = *reinterpret_cast<const float4*>(p.m2 + 4 * c4);
     float psc[KT], psh[KT];
 #pragma unroll
     for (int b = 0; b < KT; ++b) {
@@ -1505,6 +1508,11 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
         const int r0 = t * 32;
         const int rows = min(p.N - r0, 32);
         // ---- dZ tile -> LDS (rows past N are zero: they must not contribute) ----------
+        const float4 mu = *reinterpret_cast<const float4*>(coef + 4 * c4);
+        const float4 rs = *reinterpret_cast<const float4*>(coef + HP + 4 * c4);
+        const float4 ca = *reinterpret_cast<const float4*>(coef + 2 * HP + 4 * c4);
+        const float4 a1 = *reinterpret_cast<const float4*>(coef + 3 * HP + 4 * c4);
+        const float4 a2 = *reinterpret_cast<const float4*>(coef + 4 * HP + 4 * c4);
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int lrow = lrow0 + j * RSTEP;
@@ -1651,7 +1659,7 @@ template <int KT, int HT>
 static int launch_lb_pipe(const LbArgs& a, int grid, hipStream_t s) {
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
-    size_t lds = (size_t)HP * KP * 4 + (size_t)4 * 32 * XS * 4;
+    size_t lds = (size_t)HP * KP * 4 + (size_t)4 * 32 * XS * 4 + (size_t)5 * HP * 4;
     const size_t dump = ((size_t)4 * HT * KT * 1024 + (size_t)4 * HT * 64) * 4;
     if (dump > lds) lds = dump;
     GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_pipe_kernel<KT, HT>));
