@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 out=gpurun_out/matrix_$TAG.txt
 : > $out
 run() {
-  echo "== $*" >> $out
+  echo "== $* ${GNM_DENSE_FILL:+(GNM_DENSE_FILL=$GNM_DENSE_FILL: CSR gather only)}" >> $out
   timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | \
     python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), 'graphs/s', round(d['ms_per_step'],3), 'ms/step', d['launch_mode'])" >> $out
 }
@@ -22,4 +22,6 @@ run --config c4
 run --batch 32
 run --batch 32 --graph on
 run --agg0-cache
+run --graph off
+GNM_DENSE_FILL=2 run --graph off
 cat $out
