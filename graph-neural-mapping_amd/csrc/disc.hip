@@ -75,42 +75,65 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
     if constexpr (LPR4 > 0) {
         constexpr int G = 64 / LPR4;                   // rows per wave-instruction
         const int sub = lane & (LPR4 - 1), slot = lane / LPR4;
-        constexpr int ML = 8;                          // layers handled with all their loads in flight at once
+        constexpr int ML = 5;                          // layers handled with all their loads in flight at once
         float4 uu[ML];
 #pragma unroll
         for (int l = 0; l < ML; ++l)
             uu[l] = l < L ? *reinterpret_cast<const float4*>(Us + l * H + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = wave * G + slot; r < n + G - 1; r += nwaves * G) {   // uniform trip count per wave
-            const int rr = min(r, n - 1);
-            const int v = row0 + rr;
-            float a = 0.f;
-            float4 xx[ML];
+        // Two row groups in flight, ping-pong: the loads of the next group are issued BEFORE the stores of the current
+        // one, every access unconditional (a layer past L re-reads layer L - 1 against a zero U; a lane that has no
+        // result to write stores to an offset the buffer descriptor clips), so that the wait for a group's loads is a
+        // counted vmcnt and never a drain that includes the previous group's stores (gfx950 retires vector-memory
+        // operations in issue order).  The loop it replaces -- load, reduce, guarded stores, repeat -- paid an HBM
+        // write round trip per 4 rows.
+        const float* lp[ML];
 #pragma unroll
-            for (int l = 0; l < ML; ++l)               // L is wave-uniform: the row's loads are issued back to back
-                if (l < L) xx[l] = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);
-#pragma unroll
-            for (int l = 0; l < ML; ++l)
-                if (l < L) {
-                    if (tmask >> l & 1)
-                        xx[l] = gnm_bnrelu4(xx[l], *reinterpret_cast<const float4*>(Ss + l * H + 4 * sub),
-                                            *reinterpret_cast<const float4*>(Sh + l * H + 4 * sub));
-                    a += xx[l].x * uu[l].x + xx[l].y * uu[l].y + xx[l].z * uu[l].z + xx[l].w * uu[l].w;
-                }
-            for (int l = ML; l < L; ++l) {
-                float4 x = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);
-                if (tmask >> l & 1)
-                    x = gnm_bnrelu4(x, *reinterpret_cast<const float4*>(Ss + l * H + 4 * sub),
-                                    *reinterpret_cast<const float4*>(Sh + l * H + 4 * sub));
-                const float4 u = *reinterpret_cast<const float4*>(Us + l * H + 4 * sub);
-                a += x.x * u.x + x.y * u.y + x.z * u.z + x.w * u.w;
-            }
-#pragma unroll
-            for (int off = LPR4 >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
-            if (sub == 0 && r < n) {
-                d_logit[v] = a + bv;
-                d_logit[(size_t)N + v] = sc2;
-            }
+        for (int l = 0; l < ML; ++l) lp[l] = hp.p[min(l, L - 1)];
+        const __amdgpu_buffer_rsrc_t rd =
+            __builtin_amdgcn_make_buffer_rsrc(d_logit, 0, (int)((unsigned)(2 * (size_t)N * 4)), 0x00020000);
+        const int stride = nwaves * G;
+#define GNM_DS_LOAD(xx, r_)                                                                                      \
+        {                                                                                                        \
+            const size_t vo = (size_t)(row0 + min((r_), n - 1)) * ldh + 4 * sub;                                 \
+            _Pragma("unroll") for (int l = 0; l < ML; ++l) xx[l] = *reinterpret_cast<const float4*>(lp[l] + vo); \
         }
+#define GNM_DS_FINISH(xx, r_)                                                                                    \
+        {                                                                                                        \
+            const int v = row0 + min((r_), n - 1);                                                               \
+            float a = 0.f;                                                                                       \
+            _Pragma("unroll") for (int l = 0; l < ML; ++l) {                                                     \
+                float4 x = xx[l];                                                                                \
+                if (tmask >> l & 1)                                                                              \
+                    x = gnm_bnrelu4(x, *reinterpret_cast<const float4*>(Ss + min(l, L - 1) * H + 4 * sub),       \
+                                    *reinterpret_cast<const float4*>(Sh + min(l, L - 1) * H + 4 * sub));         \
+                a += x.x * uu[l].x + x.y * uu[l].y + x.z * uu[l].z + x.w * uu[l].w;                              \
+            }                                                                                                    \
+            for (int l = ML; l < L; ++l) {                                                                       \
+                float4 x = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);                \
+                if (tmask >> l & 1)                                                                              \
+                    x = gnm_bnrelu4(x, *reinterpret_cast<const float4*>(Ss + l * H + 4 * sub),                   \
+                                    *reinterpret_cast<const float4*>(Sh + l * H + 4 * sub));                     \
+                const float4 u = *reinterpret_cast<const float4*>(Us + l * H + 4 * sub);                         \
+                a += x.x * u.x + x.y * u.y + x.z * u.z + x.w * u.w;                                              \
+            }                                                                                                    \
+            _Pragma("unroll") for (int off = LPR4 >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);         \
+            const bool wr = sub == 0 && (r_) < n;                                                                \
+            const unsigned o1 = wr ? (unsigned)v * 4u : 0xFFFFFFF0u;                                             \
+            const unsigned o2 = wr ? (unsigned)(N + v) * 4u : 0xFFFFFFF0u;                                       \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a + bv), rd, o1, 0, 0);                        \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc2), rd, o2, 0, 0);                           \
+        }
+        float4 xa[ML], xb[ML];
+        int r = wave * G + slot;
+        GNM_DS_LOAD(xa, r)
+        for (; r - slot < n; r += 2 * stride) {         // wave-uniform trip count (r - slot is the wave's first row)
+            GNM_DS_LOAD(xb, r + stride)
+            GNM_DS_FINISH(xa, r)
+            GNM_DS_LOAD(xa, r + 2 * stride)
+            GNM_DS_FINISH(xb, r + stride)
+        }
+#undef GNM_DS_LOAD
+#undef GNM_DS_FINISH
     } else {
         for (int r = wave; r < n; r += nwaves) {
             const int v = row0 + r;
