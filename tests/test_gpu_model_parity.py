@@ -563,3 +563,34 @@ def test_captured_step_refuses_a_reallocated_arena():
         ar.add(g)
     with pytest.raises(RuntimeError, match="re-allocated"):
         cap.run(ar.batch_from_gids(gids), lab, np.arange(4))
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c in ("true_s0_eps1_gsum_nsum", "true_s0_eps0_gsum_naverage",
+                                                            "tiny_s0_eps1_gsum_nsum", "tiny_s1_eps0_gaverage_nsum")])
+def test_both_aggregation_paths_at_model_level(case, monkeypatch):
+    """The same train step with every batch forced onto the CSR gather (what GNM_DENSE_FILL=2 does) and on the default
+    dispatch (these dense golden graphs take the matrix-core kernel): logits and every gradient agree to fp32 rounding,
+    and the gather run is held to the fp64 oracle like the default run is elsewhere -- the CSR kernels stay covered end
+    to end now that dense batches no longer reach them."""
+    from gnm import arena as arena_mod
+    cfg, state, d = load_case(case)
+    true_shape = case.startswith("true_")
+    runs = {}
+    for path, fill in (("auto", arena_mod.DENSE_MIN_FILL), ("gather", 2.0)):
+        monkeypatch.setattr(arena_mod, "DENSE_MIN_FILL", fill)
+        model = make_model(cfg, state).train()
+        graphs = make_graphs(cfg, d)
+        batch = model.arena().batch(graphs)
+        assert batch.dense == (path == "auto"), (path, batch.dense)
+        np.random.seed(cfg["np_seed"])
+        c_logit, d_logit = model(graphs)
+        loss = c_logit.square().mean() + 0.05 * d_logit.square().mean()
+        loss.backward()
+        runs[path] = dict(c=c_logit.detach().cpu().numpy(), d=d_logit.detach().cpu().numpy(),
+                          g={k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters() if p.grad is not None})
+    tol = 20 * RTOL if true_shape else RTOL          # two fp32 implementations of a 5-layer net on 400-node graphs
+    assert_close(runs["gather"]["c"], runs["auto"]["c"], rtol=tol, what="c_logit, gather vs matrix-core")
+    assert_close(runs["gather"]["d"], runs["auto"]["d"], rtol=tol, what="d_logit, gather vs matrix-core")
+    gmax = max(float(np.abs(g).max()) for g in runs["auto"]["g"].values())
+    for k, g in runs["auto"]["g"].items():
+        assert_close(runs["gather"]["g"][k], g, rtol=5e-3 if true_shape else 5e-5, what="grad " + k, floor=2e-2 * gmax)
