@@ -63,12 +63,15 @@ __device__ __forceinline__ unsigned bf16_pair_hi(unsigned lo_word, unsigned hi_w
 
 // AVG: neighbor_pooling_type "average" (the epilogue then also loads degrees / the raw input); decided by the launcher
 // so that the "sum" forms carry none of it.
-template <bool STATS, bool AVG>
+// NARROW: F < 32 (the input layer, F0 = 7 in the benchmark): one partial column block, rows of x not 16-byte
+// addressable -- 4-byte loads with column guards, zero planes past F, stores only for columns < F.  Plain launch form
+// only (no fused prologue, no statistics, no d-eps).
+template <bool STATS, bool AVG, bool NARROW = false>
 __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- which graph / column block: the blocks of one graph sit 8 apart, i.e. on the same XCD (one L2 serves the
     //      bit matrix and the tile to all of them)
-    const int nc = p.F >> 5;                                     // 32-column blocks per graph
+    const int nc = NARROW ? 1 : p.F >> 5;                         // 32-column blocks per graph
     const int grp = blockIdx.x / (8 * nc), within = blockIdx.x - grp * (8 * nc);
     const int b = grp * 8 + (within & 7);
     const int cb = within >> 3;
@@ -147,8 +150,16 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         const int it = tid + u * kAggmThreads;
         const int rq = it >> 3;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)       // unconditional (clamped to the graph's last row; masked below): no branches
-            v[u][r] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + min(4 * rq + r, n - 1)) * p.ldx + col0 + 4 * c4);
+        for (int r = 0; r < 4; ++r) {     // unconditional (clamped to the graph's last row; masked below): no branches
+            const float* src = p.x + (size_t)(row0 + min(4 * rq + r, n - 1)) * p.ldx + col0 + 4 * c4;
+            if constexpr (!NARROW) {
+                v[u][r] = *reinterpret_cast<const float4*>(src);
+            } else {                      // columns past F: re-read the row's last column, zeroed below
+                const int cc = 4 * c4, last = p.F - 1;
+                const float* rowp = src - cc;
+                v[u][r] = make_float4(rowp[min(cc, last)], rowp[min(cc + 1, last)], rowp[min(cc + 2, last)], rowp[min(cc + 3, last)]);
+            }
+        }
     }
     // the bit rows (older in the memory queue than the tile loads just issued), packed to the bytes this half-wave
     // uses: byte m of pk[j] = step 4 j + m
@@ -169,6 +180,13 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * rq + r;
                 float4 w = row < n ? v[u][r] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (NARROW) {
+                    const int cc = 4 * c4;
+                    if (cc + 0 >= p.F) w.x = 0.f;
+                    if (cc + 1 >= p.F) w.y = 0.f;
+                    if (cc + 2 >= p.F) w.z = 0.f;
+                    if (cc + 3 >= p.F) w.w = 0.f;
+                }
                 if (row < n) {
                     if (dot_a) {
                         const float4 hh = *reinterpret_cast<const float4*>(p.hfwd + (size_t)(row0 + row) * p.ldh + col0 + 4 * c4);
@@ -334,7 +352,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                     o.dv[q] = dscp[row0 + vc];
                 }
                 if constexpr (AVG) {
-                    o.xs[q] = p.x[(size_t)(row0 + vc) * p.ldx + col];
+                    o.xs[q] = p.x[(size_t)(row0 + vc) * p.ldx + (NARROW ? min(col, p.F - 1) : col)];
                     o.d0[q] = frp[vc]; o.d1[q] = frp[vc + 1];
                 }
             }
@@ -384,7 +402,9 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                     }
                 }
                 // (row offset in the vector operand, scalar offset 0: see linear.hip, gnm_lin_stream_kernel)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ry, (vrow * p.ldy + col) * 4, 0, 0);
+                // (NARROW: a lane whose column is past F stores to an offset the descriptor clips)
+                const unsigned yoff = (NARROW && col >= p.F) ? 0xFFFFFFF0u : (unsigned)((vrow * p.ldy + col) * 4);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ry, yoff, 0, 0);
             }
         };
         Ops oa, ob;
@@ -460,7 +480,7 @@ extern "C" long long gnm_adj_bits_words(int n) {
     return W * 32 * WP;
 }
 extern "C" int gnm_aggm_max_nodes(void) { return kAggmMaxN; }
-extern "C" int gnm_aggm_num_partials(int F, int B) { return (F % 32) ? 0 : B * (F / 32); }
+extern "C" int gnm_aggm_num_partials(int F, int B) { return (F % 32) ? 0 : B * (F / 32); }   // (F < 32: no d-eps form)
 
 __global__ void __launch_bounds__(256) gnm_adj_bits_build_kernel(const int32_t* rowptr, const uint16_t* colv,
                                                                  const int64_t* g_rp_off, const int64_t* g_col_off,
@@ -504,8 +524,10 @@ extern "C" int gnm_adj_bits_build(const int32_t* rowptr, const uint16_t* col, co
 static bool aggm_shape_ok(const AggArgs& a, int n_max) {
     if (!a.adj_bits || !a.b_bits_off || (reinterpret_cast<uintptr_t>(a.adj_bits) & 15)) return false;
     if (n_max < 1 || n_max > kAggmMaxN) return false;
-    if ((a.F & 31) || a.F > 256) return false;
-    if ((a.ldx & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15)) return false;
+    const bool narrow = a.F < 32;                  // one partial column block: plain form only
+    if (narrow && (a.sZ || a.p_scale || a.deps_partial)) return false;
+    if (!narrow && ((a.F & 31) || a.F > 256)) return false;
+    if (!narrow && ((a.ldx & 3) || (reinterpret_cast<uintptr_t>(a.x) & 15))) return false;
     if (a.hfwd && ((a.ldh & 3) || (reinterpret_cast<uintptr_t>(a.hfwd) & 15))) return false;
     return true;
 }
@@ -519,14 +541,19 @@ static int launch_aggm(AggArgs a, int B, int n_max, bool stats, hipStream_t stre
     a.n_graphs = B;
     a.n16_max = ((n_max + 15) / 16) * 16;
     const size_t lds = (size_t)3 * (a.n16_max / 8) * kAggmK8Stride + kAggmScratch;
-    const int nc = a.F / 32;
+    const int nc = a.F < 32 ? 1 : a.F / 32;
     const int grid = ((B + 7) / 8) * 8 * nc;
 #define GNM_AGGM_LAUNCH(S_, A_)                                                                              \
     do {                                                                                                     \
         GNM_ALLOW_FULL_LDS((&gnm_aggm_kernel<S_, A_>));                                                      \
         hipLaunchKernelGGL((gnm_aggm_kernel<S_, A_>), dim3(grid), dim3(kAggmThreads), lds, stream, a);       \
     } while (0)
-    if (stats && a.average) GNM_AGGM_LAUNCH(true, true);
+    if (a.F < 32) {
+        GNM_ALLOW_FULL_LDS((&gnm_aggm_kernel<false, true, true>));
+        GNM_ALLOW_FULL_LDS((&gnm_aggm_kernel<false, false, true>));
+        if (a.average) hipLaunchKernelGGL((gnm_aggm_kernel<false, true, true>), dim3(grid), dim3(kAggmThreads), lds, stream, a);
+        else hipLaunchKernelGGL((gnm_aggm_kernel<false, false, true>), dim3(grid), dim3(kAggmThreads), lds, stream, a);
+    } else if (stats && a.average) GNM_AGGM_LAUNCH(true, true);
     else if (stats) GNM_AGGM_LAUNCH(true, false);
     else if (a.average) GNM_AGGM_LAUNCH(false, true);
     else GNM_AGGM_LAUNCH(false, false);

@@ -381,11 +381,24 @@ class GraphArena:
             r0 = self.feat_off[g0]
             x = self.feat.buf[r0:r0 + bt.N]                 # feature rows are stored in arena (= this batch's) order
             y = store["buf"][r0:r0 + bt.N]
-            check(lib.gnm_agg(self.rowptr.buf.data_ptr(), self.col.buf.data_ptr(), bt.rp_off.data_ptr(),
-                              bt.col_off.data_ptr(), self.rowptr.buf.data_ptr(), bt.rp_off.data_ptr(),
-                              bt.node_off.data_ptr(), bt.B, bt.n_max, bt.nnz_max, x.data_ptr(), x.stride(0),
-                              y.data_ptr(), y.stride(0), F0, None if self_loop else minus_one.data_ptr(),
-                              int(bool(average)), int(bool(self_loop)), 0, None, 0, None, st), "gnm_agg")
+            # the same kernel choice as a step that aggregates the input features itself (gnm/core.py _agg): dense
+            # batches take the matrix-core kernel, so cached and direct layer-0 values are the same bits
+            rc = -2
+            if bt.dense and (F0 < 32 or F0 % 32 == 0):
+                rc = lib.gnm_aggm(self.rowptr.buf.data_ptr(), self.col.buf.data_ptr(), bt.rp_off.data_ptr(),
+                                  bt.col_off.data_ptr(), self.bits.buf.data_ptr(), bt.bits_off.data_ptr(),
+                                  self.rowptr.buf.data_ptr(), bt.rp_off.data_ptr(), bt.node_off.data_ptr(), bt.B,
+                                  bt.n_max, x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), F0,
+                                  None if self_loop else minus_one.data_ptr(), int(bool(average)),
+                                  int(bool(self_loop)), 0, None, 0, None, st)
+                if rc not in (0, -2):
+                    check(rc, "gnm_aggm")
+            if rc == -2:
+                check(lib.gnm_agg(self.rowptr.buf.data_ptr(), self.col.buf.data_ptr(), bt.rp_off.data_ptr(),
+                                  bt.col_off.data_ptr(), self.rowptr.buf.data_ptr(), bt.rp_off.data_ptr(),
+                                  bt.node_off.data_ptr(), bt.B, bt.n_max, bt.nnz_max, x.data_ptr(), x.stride(0),
+                                  y.data_ptr(), y.stride(0), F0, None if self_loop else minus_one.data_ptr(),
+                                  int(bool(average)), int(bool(self_loop)), 0, None, 0, None, st), "gnm_agg")
         store["graphs"] = G
         return store["buf"]
 

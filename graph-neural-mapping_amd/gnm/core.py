@@ -163,8 +163,9 @@ class GinSpec:
 
 def _dense(batch, F_):
     """does this batch take the matrix-core aggregation (csrc/aggm.hip)?  The arena decides per batch (dense graphs
-    with a bit adjacency, GraphArena.batch_from_gids); the kernel wants 32-column blocks."""
-    return bool(getattr(batch, "dense", False)) and F_ % 32 == 0
+    with a bit adjacency, GraphArena.batch_from_gids); the kernel wants whole 32-column blocks, or one partial block
+    (the input layer's F0 < 32, plain form only: the fused / d-eps forms decline and the gather runs)."""
+    return bool(getattr(batch, "dense", False)) and (F_ % 32 == 0 or F_ < 32)
 
 
 def agg_partials_capacity(batch, F_):

@@ -121,8 +121,8 @@ int gnm_sum_partials(const double* partial, int count, float* out, void* stream)
  * multiplicity, keep that graph on gnm_agg).  Pass the bit matrix of the TRANSPOSED CSR for backward = 1.
  * All other arguments: exactly as in gnm_agg / gnm_agg_bwd_stats / gnm_agg_fwd_bnrelu (rowptr and the offsets are
  * still read: degrees).  deps_partial receives gnm_aggm_num_partials(F, B) doubles.
- * GNM_ERR_UNSUPPORTED (nothing launched; use the CSR form): n_max > gnm_aggm_max_nodes(), F not a multiple of 32
- * (the fused forms: F != 64), rows of x not 16-byte aligned. */
+ * GNM_ERR_UNSUPPORTED (nothing launched; use the CSR form): n_max > gnm_aggm_max_nodes(); F neither a multiple of 32
+ * with 16-byte aligned rows of x nor < 32 (F < 32, the input layer: gnm_aggm without d-eps only; the fused forms: F = 64). */
 long long gnm_adj_bits_words(int n);
 int gnm_aggm_max_nodes(void);
 int gnm_aggm_num_partials(int F, int B);

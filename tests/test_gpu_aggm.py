@@ -67,6 +67,9 @@ AGGM_CASES = [
     ([300, 130], 0.15, 128, True),           # four column blocks
     ([45, 45, 45], 0.3, 64, False),          # asymmetric: backward runs on the transposed bit matrix
     ([17] * 11, 0.5, 64, True),              # more graphs than one XCD round
+    ([400, 400], 0.3, 7, True),              # the input layer: one partial column block, unaligned rows
+    ([37, 5, 64, 1, 23], 0.4, 5, True),
+    ([45, 45, 45], 0.3, 20, False),
 ]
 
 
@@ -119,7 +122,10 @@ def test_aggm_forward_backward(sizes, density, F, symmetric, average, learn_eps)
     part = torch.full((core.agg_partials_capacity(batch, F),), float("nan"), dtype=torch.float64, device=DEV)
     cnt = core._agg(batch, dpd, dhd, F, epsd.data_ptr() if learn_eps else None, spec, backward=True,
                     hfwd=xd if learn_eps else None, deps_partial=part if learn_eps else None)
-    assert cnt == core.lib.gnm_aggm_num_partials(F, batch.B) == batch.B * (F // 32)
+    if F % 32 == 0:
+        assert cnt == core.lib.gnm_aggm_num_partials(F, batch.B) == batch.B * (F // 32)
+    elif learn_eps:      # narrow F with d eps: the matrix-core form declines, the CSR gather ran
+        assert cnt == core.lib.gnm_agg_num_partials(F, batch.n_max, batch.B)
     dp64 = dp.astype(np.float64)
     with np.errstate(divide="ignore", invalid="ignore"):
         if learn_eps:
@@ -310,7 +316,8 @@ def test_aggm_refuses_what_it_does_not_cover():
                             None, 0, 1, 0, None, 0, None, _stream())
     assert call(30, 64, 64) == 0
     assert call(417, 64, 64) == -2          # larger than the LDS planes allow
-    assert call(30, 20, 64) == -2           # not whole 32-column blocks
+    assert call(30, 40, 64) == -2           # neither whole 32-column blocks nor one partial block
+    assert call(30, 20, 64) == 0            # one partial block (F < 32)
     assert call(30, 32, 62) == -2           # rows not 16-byte aligned
     assert call(30, 64, 64, bits=False) == -2
     # a sparse batch is left to the gather by the arena
