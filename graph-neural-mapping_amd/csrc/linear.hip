@@ -427,7 +427,10 @@ static int launch_lin_fast(const LinArgs& a, int grid, hipStream_t s) {
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gnm_tile_rsrc(const float* base, long long rows, int ld, int width) {
-    // raw buffer (stride 0): byte offsets >= num_records read 0 / are not written
+    // raw buffer (stride 0): byte offsets >= num_records read 0 / are not written.  On gfx950 the check covers the
+    // scalar offset too (tools/ubench/soffset_check.hip: a load that leaves the range only through soffset returns 0),
+    // so the loads below may carry their row step in soffset; the STORES carry it in the vector offset for another
+    // reason (the data-register hazard described at gnm_lin_stream_kernel).
     const unsigned bytes = rows > 0 ? (unsigned)(((rows - 1) * ld + width) * 4) : 0u;
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
