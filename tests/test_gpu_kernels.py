@@ -696,11 +696,14 @@ def test_full_size_aggregation_properties(full_batch):
 
 
 def test_full_size_model_step_runs_and_is_deterministic(full_batch):
-    """One full training step at BASELINE configs[1] size; two runs agree bitwise."""
+    """One full training step at BASELINE configs[1] size; six runs agree bitwise.  (Only this size runs the
+    persistent-grid loops of the Linear kernels for several tiles per wave and keeps all 256 CUs busy: it is the test
+    that caught the buffer-store hazard of the streaming kernel -- wrong values in ~1 % of the tiles, different ones in
+    every launch -- which no small case could show.)"""
     from models.graphcnn import GIN_InfoMaxReg
     pool, ar, _ = full_batch
     outs = []
-    for _ in range(2):
+    for _ in range(6):
         torch.manual_seed(0)
         model = GIN_InfoMaxReg(5, 2, 7, 64, 2, 0.0, True, "sum", "sum", torch.device(DEV)).to(DEV).train()
         arena = model.arena()
@@ -710,5 +713,6 @@ def test_full_size_model_step_runs_and_is_deterministic(full_batch):
         assert c.shape == (1024, 2) and d.shape == (2 * 409600, 1)
         (c.square().mean() + d.square().mean()).backward()
         outs.append([c.detach().clone(), d.detach().clone()] + [p.grad.clone() for p in model.parameters()])
-    for a, b in zip(*outs):
-        assert torch.isfinite(a).all() and torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.isfinite(a).all() and torch.equal(a, b)
