@@ -716,3 +716,61 @@ def test_full_size_model_step_runs_and_is_deterministic(full_batch):
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N", [150001, 98304])
+def test_linear_kernels_many_tiles_per_wave(N):
+    """The persistent-grid Linear kernels at a size where every wave walks several 32-row tiles (the small cases above
+    give each wave at most one, i.e. only the peeled first iteration of gnm_lin_stream_kernel and
+    gnm_linear_bwd_pipe_kernel): forward with prologue + statistics, fused backward without statistics (pipelined
+    kernel) and the second-Linear form (lower BatchNorm's mask and sums from the operand registers), against fp64 torch
+    products on the GPU.  150,001 rows end in a partial tile.  dW / db sum 1.5e5 fp32 products: 5e-5."""
+    from gnm import core
+    from gnm._cabi import check, lib
+    K = H = 64
+    g = torch.Generator(device=DEV).manual_seed(N)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    X, W, b = rn(N, K), rn(H, K) / 8, rn(H)
+    sc, sh = torch.rand(K, device=DEV, generator=g) + 0.5, rn(K) * 0.3
+    Z = torch.full((N, H), float("nan"), device=DEV)
+    grid = lib.gnm_linear_grid(N)
+    stats = torch.zeros((grid, 2, H), dtype=torch.float64, device=DEV)
+    core._linear(X, W, 0, b, Z, N, K, H, (sc, sh), stats)
+    Xe = torch.relu(X * sc + sh).double()
+    ref = Xe @ W.double().t() + b.double()
+    assert_close(Z.cpu().numpy(), ref.cpu().numpy(), rtol=TOL, what="linear fwd")
+    st = stats.sum(0)
+    assert_close(st[0].cpu().numpy(), Z.double().sum(0).cpu().numpy(), rtol=1e-6, what="column sums")
+    assert_close(st[1].cpu().numpy(), (Z.double() ** 2).sum(0).cpu().numpy(), rtol=1e-6, what="column sums of squares")
+    # fused backward
+    G, Zb = rn(N, H), rn(N, H) * 1.5 + 0.5
+    mean, rstd = Zb.mean(0), 1 / torch.sqrt(Zb.var(0, unbiased=False) + 1e-5)
+    cA, m1, m2 = torch.rand(H, device=DEV, generator=g) + 0.5, G.mean(0), rn(H) * 0.1
+    dZ = cA.double() * (G.double() - m1.double() - (Zb.double() - mean.double()) * rstd.double() * m2.double())
+    ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, H, K)), device=DEV)
+    lmean, lrstd = rn(K) * 0.1, torch.rand(K, device=DEV, generator=g) + 0.5
+    for form in ("no statistics, raw input", "second Linear of an MLP"):
+        second = form.startswith("second")
+        dA = torch.full((N, K), float("nan"), device=DEV)
+        dW = torch.full((H, K), float("nan"), device=DEV)
+        db = torch.full((H,), float("nan"), device=DEV)
+        lp = torch.full((lib.gnm_linear_bwd_grid(N), 2, K), float("nan"), dtype=torch.float64, device=DEV)
+        check(lib.gnm_linear_bwd_fused(
+            G.data_ptr(), H, Zb.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(),
+            m2.data_ptr(), X.data_ptr(), K, sc.data_ptr() if second else None, sh.data_ptr() if second else None,
+            1 if second else 0, W.data_ptr(), K, dA.data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, K, H,
+            X.data_ptr() if second else None, K if second else 0, sc.data_ptr() if second else None,
+            sh.data_ptr() if second else None, lmean.data_ptr() if second else None,
+            lrstd.data_ptr() if second else None, lp.data_ptr() if second else None, _stream()), form)
+        Xin = Xe if second else X.double()
+        dX_ref = dZ @ W.double()
+        if second:
+            mask = (X * sc + sh > 0)
+            dX_ref = dX_ref * mask
+            s_ref = torch.stack([dX_ref.sum(0), (dX_ref * ((X.double() - lmean.double()) * lrstd.double())).sum(0)])
+            fl = 1e-3 * float(dX_ref.abs().sum(0).max())
+            assert_close(lp.sum(0).cpu().numpy(), s_ref.cpu().numpy(), rtol=TOL, what=form + ": lower BatchNorm sums", floor=fl)
+        assert_close(dA.cpu().numpy(), dX_ref.cpu().numpy(), rtol=TOL, what=form + ": dX")
+        assert_close(dW.cpu().numpy(), (dZ.t() @ Xin).cpu().numpy(), rtol=5e-5, what=form + ": dW")
+        assert_close(db.cpu().numpy(), dZ.sum(0).cpu().numpy(), rtol=5e-5, what=form + ": db",
+                     floor=1e-2 * float(dZ.abs().sum(0).max()))
