@@ -669,11 +669,18 @@ def full_batch():
     return pool, ar, batch
 
 
-def test_full_size_aggregation_properties(full_batch):
+@pytest.mark.parametrize("path", ["matrix-core", "gather"])
+def test_full_size_aggregation_properties(full_batch, path):
     """B = 1024 x (n = 400, E = 47,600): exact edge count, linearity, the degree-weighted
-    column checksum sum_v (A x)_v = sum_u deg(u) x_u (symmetric graphs), and determinism."""
+    column checksum sum_v (A x)_v = sum_u deg(u) x_u (symmetric graphs), and determinism -- on the kernel these dense
+    graphs take by default (csrc/aggm.hip) and on the CSR gather (csrc/agg.hip)."""
+    import copy
     from gnm import core
     pool, ar, batch = full_batch
+    assert batch.dense
+    if path == "gather":
+        batch = copy.copy(batch)
+        batch.dense = False
     assert all(int(g.edge_mat.shape[1]) == 47600 for g in pool)          # SURVEY 8(d)
     N, F = batch.N, 64
     assert N == 409600
