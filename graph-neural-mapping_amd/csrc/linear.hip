@@ -1754,10 +1754,80 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
         rc = samez ? launch_lb<2, 2, true, false, true>(a, grid, s)
                    : (sZ ? launch_lb<2, 2, true>(a, grid, s) : launch_lb<2, 2, false>(a, grid, s));
     if (rc != GNM_OK) return rc;
+    if (!dW) return GNM_OK;      // deferred: the partials stay in `workspace` for gnm_reduce_partials_multi
     const long long stride = (long long)H * K + H;
     const int count = H * K + H;
     hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 31) / 32), dim3(1024), 0, s, workspace, grid, stride,
                        H, K, 0, dW, lddw, db);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// The dW / db partial reductions of several gnm_linear_bwd_fused calls (dW = NULL there) in ONE launch: nothing in
+// the backward depends on a weight gradient, so the ten ~5-us reductions of a step need not sit between its kernels.
+// Same summation order per element as gnm_reduce_partials_kernel.
+#define GNM_MAX_REDUCE_JOBS 32
+struct ReduceJobs {
+    const float* partial[GNM_MAX_REDUCE_JOBS];
+    float* dW[GNM_MAX_REDUCE_JOBS];
+    float* db[GNM_MAX_REDUCE_JOBS];
+    int nblk[GNM_MAX_REDUCE_JOBS], H[GNM_MAX_REDUCE_JOBS], K[GNM_MAX_REDUCE_JOBS], ldw[GNM_MAX_REDUCE_JOBS];
+    int first_block[GNM_MAX_REDUCE_JOBS + 1];
+    int njobs;
+};
+__global__ void __launch_bounds__(1024) gnm_reduce_partials_multi_kernel(const ReduceJobs J) {
+    __shared__ float red[32][32];
+    int j = 0;
+    while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;      // workgroup-uniform
+    const float* __restrict__ partial = J.partial[j];
+    const int nblk = J.nblk[j], H = J.H[j], kw = J.K[j];
+    const long long stride = (long long)H * kw + H;
+    const int tid = threadIdx.x;
+    const int grp = tid >> 5, ngrp = (int)blockDim.x >> 5;
+    const int e = ((int)blockIdx.x - J.first_block[j]) * 32 + (tid & 31);
+    const int count = H * kw + H;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < count) {
+        int b = grp;
+        for (; b + 3 * ngrp < nblk; b += 4 * ngrp) {
+            const float v0 = partial[(size_t)(b + 0 * ngrp) * stride + e], v1 = partial[(size_t)(b + 1 * ngrp) * stride + e];
+            const float v2 = partial[(size_t)(b + 2 * ngrp) * stride + e], v3 = partial[(size_t)(b + 3 * ngrp) * stride + e];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        }
+        for (; b < nblk; b += ngrp) s0 += partial[(size_t)b * stride + e];
+    }
+    red[grp][tid & 31] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (tid < 32 && e < count) {
+        float s = 0.f;
+        for (int g = 0; g < ngrp; ++g) s += red[g][tid];
+        if (e < H * kw) {
+            const int row = e / kw, col = e - row * kw;
+            J.dW[j][(size_t)row * J.ldw[j] + col] = s;
+        } else if (J.db[j]) {
+            J.db[j][e - H * kw] = s;
+        }
+    }
+}
+
+// workspaces[i]: the workspace of the i-th gnm_linear_bwd_fused(N, K = Ks[i], H = Hs[i], dW = NULL) call of the same N.
+extern "C" int gnm_reduce_partials_multi(const float* const* workspaces_host, float* const* dW_host, const int* lddw_host,
+                                         float* const* db_host, const int* Hs_host, const int* Ks_host, int njobs, int N,
+                                         void* stream) {
+    if (njobs <= 0) return GNM_OK;
+    if (njobs > GNM_MAX_REDUCE_JOBS || N <= 0) return GNM_ERR_BAD_ARG;
+    ReduceJobs J;
+    int blocks = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (!workspaces_host[i] || !dW_host[i] || Hs_host[i] <= 0 || Ks_host[i] <= 0) return GNM_ERR_BAD_ARG;
+        J.partial[i] = workspaces_host[i]; J.dW[i] = dW_host[i]; J.db[i] = db_host[i];
+        J.nblk[i] = gnm_linear_bwd_grid(N); J.H[i] = Hs_host[i]; J.K[i] = Ks_host[i]; J.ldw[i] = lddw_host[i];
+        J.first_block[i] = blocks;
+        blocks += (Hs_host[i] * Ks_host[i] + Hs_host[i] + 31) / 32;
+    }
+    J.first_block[njobs] = blocks;
+    J.njobs = njobs;
+    hipLaunchKernelGGL(gnm_reduce_partials_multi_kernel, dim3(blocks), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), J);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }

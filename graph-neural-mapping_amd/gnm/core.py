@@ -12,6 +12,7 @@ Every N-sized array op runs in libgnm_hip.so.  There is no CPU or eager-PyTorch 
 for the sum/average path: on a non-GPU tensor the calls raise.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn.functional as F
@@ -20,6 +21,9 @@ from ._cabi import GnmError, check, lib, ptr
 
 BN_EPS = 1e-5       # nn.BatchNorm1d defaults (mlp.py:38, graphcnn.py:51)
 BN_MOMENTUM = 0.1
+# the dW / db partials of the fused Linear backwards are reduced by ONE launch at the end of the backward
+# (GNM_NO_DEFER_REDUCE=1: one launch after each Linear, for A/B timing)
+DEFER_WGRAD_REDUCE = os.environ.get("GNM_NO_DEFER_REDUCE") is None
 
 
 _STREAM = None      # raw hipStream_t of torch's current stream, fetched once per forward / backward
@@ -591,6 +595,7 @@ class GinInfoMaxFn(torch.autograd.Function):
         dH_next = None
         dX = None
         pre_outer = None
+        wjobs = []          # (workspace, dW, db, H, K) of the fused Linear backwards whose partial reduction is deferred
         for l in reversed(range(L)):
             h_in, pooled, lins = saved[l]            # h_in: this layer's input (X, an array, or a ZAct)
             F_l = h_in.shape[1]
@@ -662,7 +667,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                         sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), sv.x_in.data_ptr(),
                         sv.x_in.stride(0), ptr(sv.pro[0]) if sv.pro else None, ptr(sv.pro[1]) if sv.pro else None,
                         1 if sv.pro else 0, W.data_ptr(), W.stride(0), ptr(dA), dA.stride(0) if need_dA else 0,
-                        dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), N, K, Hk,
+                        None if DEFER_WGRAD_REDUCE else dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), N, K, Hk,
                         lo.z.data_ptr() if lo_part is not None else None, lo.z.stride(0) if lo_part is not None else 0,
                         lo.scale.data_ptr() if lo_part is not None else None,
                         lo.shift.data_ptr() if lo_part is not None else None,
@@ -670,6 +675,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                         lo.rstd.data_ptr() if lo_part is not None else None, ptr(lo_part), st)
                     if rc != 0:
                         tm.cancel()
+                if rc == 0 and DEFER_WGRAD_REDUCE:
+                    wjobs.append((ws, dW, db, Hk, K))       # its dW / db partials: one reduction launch after the loop
                 if rc == 0 and lo_part is not None:
                     pre_stats = (dA, lo_part, lo_part.shape[0])
                 if rc == -2:        # GNM_ERR_UNSUPPORTED: generic three-kernel path
@@ -768,6 +775,14 @@ class GinInfoMaxFn(torch.autograd.Function):
                     dH_next = dh
                 else:
                     dX = dh
+        for j0 in range(0, len(wjobs), 32):
+            jb = wjobs[j0:j0 + 32]
+            nj = len(jb)
+            check(lib.gnm_reduce_partials_multi(
+                (C.c_void_p * nj)(*[j[0].data_ptr() for j in jb]), (C.c_void_p * nj)(*[j[1].data_ptr() for j in jb]),
+                (C.c_int * nj)(*[j[1].stride(0) for j in jb]), (C.c_void_p * nj)(*[j[2].data_ptr() for j in jb]),
+                (C.c_int * nj)(*[j[3] for j in jb]), (C.c_int * nj)(*[j[4] for j in jb]), nj, N, st),
+                "gnm_reduce_partials_multi")
         if spec.learn_eps:
             # layers whose aggregation backward did not run (no incoming gradient) have count 0 -> d eps = 0
             check(lib.gnm_sum_partials_multi(eps_parts.data_ptr(), eps_parts.stride(0), (C.c_int * L)(*eps_counts), L,

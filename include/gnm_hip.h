@@ -190,6 +190,12 @@ int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int ldz, const
                          float* dA, int lda, float* dW, int lddw, float* db, float* workspace, int N, int K, int H,
                          const float* sZ, int ldsz, const float* s_scale, const float* s_shift, const float* s_mean,
                          const float* s_rstd, double* s_partial, void* stream);
+/* dW = NULL defers the reduction of the per-workgroup dW / db partials: they stay in `workspace` (keep it alive and
+ * unshared) until ONE gnm_reduce_partials_multi call reduces up to 32 such workspaces of the same N, e.g. at the end
+ * of a backward pass (nothing in the backward reads a weight gradient).  HOST arrays of njobs entries. */
+int gnm_reduce_partials_multi(const float* const* workspaces_host, float* const* dW_host, const int* lddw_host,
+                              float* const* db_host, const int* Hs_host, const int* Ks_host, int njobs, int N,
+                              void* stream);
 /* sZ (optional): dA is the gradient arriving at relu(bn_lo(sZ)), the BatchNorm+ReLU feeding this Linear
  * (mlp.py:48).  Then dA is written already multiplied by that ReLU mask and s_partial receives
  * [gnm_linear_bwd_grid(N)][2][K] doubles (sum g, sum g*xhat) for gnm_bn_bwd_finalize -- i.e. the call also

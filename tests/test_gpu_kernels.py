@@ -375,6 +375,43 @@ def test_linear_backward_fused(N, K, H, pro, want_dx):
             assert_close(dW3.cpu().numpy(), dZ.T @ Xe, rtol=TOL, what="dW (sZ = X)")
 
 
+def test_linear_backward_deferred_weight_reduction():
+    """dW = NULL leaves the per-workgroup partials in the workspace; gnm_reduce_partials_multi reduces several
+    calls' partials in one launch and must give the bits of the immediate reduction."""
+    import ctypes as C
+    from gnm._cabi import check, lib
+    N = 5000
+    rng = np.random.default_rng(5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(DEV)
+    jobs = []
+    for K, H in [(64, 64), (7, 64), (32, 64), (64, 32)]:
+        G, Z, X = t(rng.standard_normal((N, H))), t(rng.standard_normal((N, H))), t(rng.standard_normal((N, K)))
+        W = t(rng.standard_normal((H, K)) / np.sqrt(K))
+        vec = [t(rng.uniform(0.5, 1.5, H)) for _ in range(5)]
+        got = []
+        for defer in (False, True):
+            dW = torch.full((H, K + 3), float("nan"), device=DEV)          # a row stride that is not K
+            db = torch.full((H,), float("nan"), device=DEV)
+            ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, H, K)), device=DEV)
+            dA = torch.empty(N, K, device=DEV)
+            check(lib.gnm_linear_bwd_fused(G.data_ptr(), H, Z.data_ptr(), H, *[v.data_ptr() for v in vec], X.data_ptr(), K,
+                                           None, None, 0, W.data_ptr(), K, dA.data_ptr(), K,
+                                           None if defer else dW.data_ptr(), K + 3, db.data_ptr(), ws.data_ptr(), N, K, H,
+                                           None, 0, None, None, None, None, None, _stream()), "linear_bwd_fused")
+            got.append((dW, db, ws))
+        assert torch.isnan(got[1][0]).all() and torch.isnan(got[1][1]).all()       # deferred: nothing written yet
+        jobs.append((got[0], got[1], H, K))
+    nj = len(jobs)
+    check(lib.gnm_reduce_partials_multi(
+        (C.c_void_p * nj)(*[j[1][2].data_ptr() for j in jobs]), (C.c_void_p * nj)(*[j[1][0].data_ptr() for j in jobs]),
+        (C.c_int * nj)(*[j[3] + 3 for j in jobs]), (C.c_void_p * nj)(*[j[1][1].data_ptr() for j in jobs]),
+        (C.c_int * nj)(*[j[2] for j in jobs]), (C.c_int * nj)(*[j[3] for j in jobs]), nj, N, _stream()), "reduce_multi")
+    for now, later, H, K in jobs:
+        assert torch.equal(now[0][:, :K], later[0][:, :K]) and torch.equal(now[1], later[1])
+        assert torch.isnan(later[0][:, K:]).all()
+    assert lib.gnm_reduce_partials_multi(None, None, None, None, None, None, 33, N, _stream()) != 0
+
+
 @pytest.mark.parametrize("sizes,H", [([40, 40, 40], 64), ([13, 50, 7], 32), ([300, 300], 128), ([1], 64)])
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("average", [0, 1])
