@@ -39,6 +39,10 @@ SIGNATURES = {
     "gnm_rowdot_num_partials": (_i, []),
     "gnm_rowdot_partials": (_i, [_p, _i, _p, _i, _ll, _i, _p, _p]),
     "gnm_sum_partials_multi": (_i, [_p, _ll, _p, _i, _p, _p]),
+    "gnm_maxpool_colmin_blocks": (_i, [_i]),
+    "gnm_maxpool_colmin": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "gnm_maxpool_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
+    "gnm_maxpool_bwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "gnm_linear_grid": (_i, [_i]),
     "gnm_linear_max_k": (_i, [_i]),
     "gnm_linear_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),

@@ -68,7 +68,8 @@ class Batch:
     """What the kernels need to know about one batch of graphs (all on the device)."""
 
     __slots__ = ("B", "N", "n_max", "n_min", "nnz_max", "arena", "node_off", "rp_off", "col_off", "t_rp_off",
-                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base", "bits_off", "t_bits_off", "dense")
+                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base", "bits_off", "t_bits_off", "dense", "maxnb")
+    # maxnb: gnm.maxnb.MaxNeighbours of the batch when the model pools neighbours with "max" (set by forward())
     # dense: every graph has a bit adjacency and the batch is dense enough for the matrix-core aggregation
     # (DENSE_MIN_FILL); bits_off / t_bits_off: int64 [B] offsets of the forward / transposed bit matrices in arena.bits
     # feat_base: int64 [B], first row of each graph's node features in the arena's feature buffer.  Part of the

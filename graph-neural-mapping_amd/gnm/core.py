@@ -150,6 +150,9 @@ class GinSpec:
         self.learn_eps = bool(learn_eps)
         self.g_avg = graph_pooling_type == "average"
         self.n_avg = neighbor_pooling_type == "average"
+        # "max" (graphcnn.py:137-143): csrc/maxpool.hip over batch.maxnb (gnm/maxnb.py) in place of the aggregation
+        # kernels; the BatchNorm + ReLU of the layer below then runs as its own kernel
+        self.n_max = neighbor_pooling_type == "max"
         # Optional gradient sink {parameter name: tensor}: when set (gnm.parallel.DataParallelGIN
         # points it at views of its flat gradient buffer) the backward kernels write every parameter
         # gradient straight into these tensors (OVERWRITING them) and autograd gets None, instead of
@@ -213,6 +216,50 @@ def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None)
     return int(lib.gnm_agg_num_partials(F_, batch.n_max, batch.B))
 
 
+def _max_fwd(batch, h, pooled, F_, eps_ptr):
+    """pooled = max over the neighbour rows of h [+ (1 + eps) h] (graphcnn.py:137-143, 149-151/161, 173-175).
+    Returns (amax, amin): the selected row of every element and torch.min's row per column -- where the backward
+    sends the gradient."""
+    mb = getattr(batch, "maxnb", None)
+    if mb is None or mb.N != batch.N:
+        raise GnmError("neighbor_pooling_type='max' needs the graphs' neighbour lists: call forward(batch_graph)")
+    N = batch.N
+    dev = h.device
+    dummy = amin = None
+    if mb.need_dummy:                                   # some row is padded: dummy = torch.min(h, dim=0)[0]  (:140)
+        nblk = int(lib.gnm_maxpool_colmin_blocks(N))
+        wv = torch.empty((nblk, F_), dtype=torch.float32, device=dev)
+        wi = torch.empty((nblk, F_), dtype=torch.int32, device=dev)
+        dummy = torch.empty(F_, dtype=torch.float32, device=dev)
+        amin = torch.empty(F_, dtype=torch.int32, device=dev)
+        check(lib.gnm_maxpool_colmin(h.data_ptr(), h.stride(0), N, F_, wv.data_ptr(), wi.data_ptr(), dummy.data_ptr(),
+                                     amin.data_ptr(), _stream()), "gnm_maxpool_colmin")
+    if mb.max_deg == 0 and not mb.self_last and N > 0:
+        raise IndexError("max(): Expected reduction dim 1 to have non-zero size.")     # what torch.max raises (:142)
+    amax = torch.empty((N, F_), dtype=torch.int32, device=dev)
+    with _timed("maxpool_fwd_F%d" % F_, F=F_, B=batch.B, N=N):
+        check(lib.gnm_maxpool_fwd(h.data_ptr(), h.stride(0), mb.nb_off.data_ptr(), mb.nb_col.data_ptr(), N, F_,
+                                  mb.max_deg, int(mb.self_last), eps_ptr, ptr(dummy), pooled.data_ptr(),
+                                  pooled.stride(0), amax.data_ptr(), _stream()), "gnm_maxpool_fwd")
+    return amax, amin
+
+
+def _max_bwd(batch, dpooled, dh, F_, eps_ptr, aux, hfwd, deps_partial):
+    """d h from d pooled through the selection recorded by _max_fwd; d eps partials as a flat dot product.
+    Returns the number of d-eps partials written."""
+    mb = batch.maxnb
+    amax, amin = aux
+    with _timed("maxpool_bwd_F%d" % F_, F=F_, B=batch.B, N=batch.N):
+        check(lib.gnm_maxpool_bwd(dpooled.data_ptr(), dpooled.stride(0), amax.data_ptr(), mb.t_off.data_ptr(),
+                                  mb.t_col.data_ptr(), batch.N, F_, eps_ptr, ptr(mb.iso_rows), mb.n_iso, ptr(amin),
+                                  dh.data_ptr(), dh.stride(0), _stream()), "gnm_maxpool_bwd")
+    if deps_partial is None:
+        return 0
+    check(lib.gnm_rowdot_partials(dpooled.data_ptr(), dpooled.stride(0), hfwd.data_ptr(), hfwd.stride(0), batch.N, F_,
+                                  deps_partial.data_ptr(), _stream()), "gnm_rowdot_partials")
+    return int(lib.gnm_rowdot_num_partials())
+
+
 def _linear(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
     with _timed("lin_%s_K%d_H%d" % ("dgrad" if w_kmajor else "fwd", K, H), N=N, K=K, H=H):
         check(lib.gnm_linear_fwd(x.data_ptr(), x.stride(0), W.data_ptr(), W.stride(0), int(w_kmajor), ptr(bias),
@@ -263,6 +310,7 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
     for l in range(L):
         F_l = h.shape[1]
         eps_ptr = P["eps"].data_ptr() + 4 * l if spec.learn_eps else None
+        aux = None          # max pooling: what its backward needs
         if l == 0 and P0 is not None:
             # A X [/deg] comes from the arena's cache; only the (1 + eps_0) X self term depends on a parameter
             pooled = torch.addcmul(P0, h, P["eps"][0:1] + 1.0) if spec.learn_eps else P0
@@ -275,7 +323,7 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
                 z, scale, shift, hout, gslice = pending
                 hout_ptr, hout_ld = (hout.data_ptr(), hout.stride(0)) if hout is not None else (None, 0)
                 rc = -2
-                if _dense(batch, F_l):
+                if _dense(batch, F_l) and not spec.n_max:
                     with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1, mfma=1) as tm:
                         rc = lib.gnm_aggm_fwd_bnrelu(
                             a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
@@ -286,7 +334,7 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
                             int(not spec.learn_eps), _stream())
                         if rc != 0:
                             tm.cancel()
-                if rc == -2:
+                if rc == -2 and not spec.n_max:
                     with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1) as tm:
                         rc = lib.gnm_agg_fwd_bnrelu(
                             a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
@@ -306,7 +354,9 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
                     check(rc, "gnm_agg_fwd_bnrelu")
                     fused = True
                 pending = None
-            if not fused:
+            if spec.n_max:
+                aux = _max_fwd(batch, hidden_tensor(h), pooled, F_l, eps_ptr)
+            elif not fused:
                 _agg(batch, hidden_tensor(h), pooled, F_l, eps_ptr, spec, backward=False)    # graphcnn.py:154-161 / 178-182
         x_in, pro, lins = pooled, None, []
         for k in range(m):                                                   # mlp.py:40-49
@@ -347,7 +397,7 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
             hout = torch.empty((N, H), **f32) if getattr(spec, "keep_hidden", False) else None
             readout(x_in, pro[0], pro[1], hout, gslice)
             hnew = hout if hout is not None else ZAct(x_in, pro[0], pro[1])
-        saved.append((h, pooled, lins))
+        saved.append((h, pooled, lins, aux))
         hidden.append(hnew)
         h = hnew
     return hidden, g_f, saved
@@ -597,7 +647,7 @@ class GinInfoMaxFn(torch.autograd.Function):
         pre_outer = None
         wjobs = []          # (workspace, dW, db, H, K) of the fused Linear backwards whose partial reduction is deferred
         for l in reversed(range(L)):
-            h_in, pooled, lins = saved[l]            # h_in: this layer's input (X, an array, or a ZAct)
+            h_in, pooled, lins, aux = saved[l]       # h_in: this layer's input (X, an array, or a ZAct)
             F_l = h_in.shape[1]
             incoming = dH_next                       # grad wrt this layer's output from the layer above
             # (G, partial, nblk) when the producer of this gradient already applied the ReLU mask and reduced
@@ -710,7 +760,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                     part = eps_parts[l]
                 eps_ptr = P["eps"].data_ptr() + 4 * l if spec.learn_eps else None
                 fused = False
-                if l > 0 and want_dh:
+                if l > 0 and want_dh and not spec.n_max:
                     # also do the layer below's outer-BatchNorm backward pass 1 in the same kernel
                     lo = saved[l - 1][2][-1]
                     use_disc = dsc1 is not None
@@ -766,6 +816,11 @@ class GinInfoMaxFn(torch.autograd.Function):
                         check(lib.gnm_rowdot_partials(dpooled.data_ptr(), dpooled.stride(0), hin_t.data_ptr(),
                                                       hin_t.stride(0), N, F_l, part.data_ptr(), st),
                               "gnm_rowdot_partials")
+                elif spec.n_max:
+                    cnt = _max_bwd(batch, dpooled, dh, F_l, eps_ptr, aux,
+                                   hidden_tensor(h_in) if spec.learn_eps else None, part)
+                    if spec.learn_eps:
+                        eps_counts[l] = cnt
                 elif not fused:
                     cnt = _agg(batch, dpooled, dh, F_l, eps_ptr, spec, backward=True,
                                hfwd=hidden_tensor(h_in) if spec.learn_eps else None, deps_partial=part)

@@ -85,7 +85,7 @@ class DataParallelGIN:
         # AccumulateGrad adds are needed; see GinSpec.grad_sink)
         self.direct = False
         spec = getattr(model, "_spec", None)
-        if direct_grads and spec is not None and getattr(model, "neighbor_pooling_type", "max") != "max":
+        if direct_grads and spec is not None:
             sink, off = {}, 0
             names = [n for n, _ in model.named_parameters()]
             for n, p in zip(names, self.fp.params):

@@ -9,10 +9,12 @@ graphcnn.py:199), return values and error behaviour follow the reference.
 
 What differs is how the work is done: graphs are converted once to a device-resident CSR
 arena (gnm/arena.py), and everything from `X_concat` on runs in libgnm_hip.so through one
-autograd.Function with a hand-written backward (gnm/core.py).  The sum / average
-neighbour-pooling paths have no CPU or eager fallback -- on a CPU device forward() raises.
-neighbor_pooling_type == "max" is outside the accelerated path and
-runs as plain torch ops, for API compatibility only.
+autograd.Function with a hand-written backward (gnm/core.py).  There is no CPU or eager
+fallback -- on a CPU device forward() raises.  neighbor_pooling_type == "max" (outside
+BASELINE.json's north_star) runs through the same engine with
+csrc/maxpool.hip in place of the aggregation kernels (gnm/maxnb.py builds its neighbour
+lists from graph.neighbors, as graphcnn.py:55-81 does); only the hipGraph replays and the
+layer-0 cache are not offered for it.
 """
 import os
 import sys
@@ -20,7 +22,6 @@ import sys
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG = os.path.dirname(_HERE)
@@ -73,8 +74,7 @@ class GIN_InfoMaxReg(nn.Module):
     def __init__(self, num_layers, num_mlp_layers, input_dim, hidden_dim, output_dim, final_dropout, learn_eps,
                  graph_pooling_type, neighbor_pooling_type, device):
         super().__init__()
-        if neighbor_pooling_type != "max":
-            self._check_kernel_limits(num_layers, input_dim, hidden_dim)
+        self._check_kernel_limits(num_layers, input_dim, hidden_dim)
         # creation order follows graphcnn.py:29-52 so torch.manual_seed(s) yields the same weights
         self.disc = Discriminator(hidden_dim * num_layers)
         self.sigm = nn.Sigmoid()
@@ -152,7 +152,9 @@ class GIN_InfoMaxReg(nn.Module):
         if perm is None:
             perm = np.random.permutation(batch.B)                             # graphcnn.py:199
         P0 = None
-        if X is None:
+        if X is None and self._spec.n_max:
+            X = batch.arena.features(batch)
+        elif X is None:
             # layer 0's A X [/deg] does not depend on the parameters: gathered from the arena's per-graph cache
             X, P0 = batch.arena.features_and_agg0(batch, self._spec.n_avg, not self._spec.learn_eps)
         c_logit, d_logit, g_f = self._run(batch, X, perm, want_disc=True, P0=P0)
@@ -229,95 +231,31 @@ class GIN_InfoMaxReg(nn.Module):
         return c_logit, d_logit
 
     # ------------------------------------------------------------------ reference API
+    def _batch_of(self, batch_graph):
+        batch = self.arena().batch(batch_graph)
+        if self._spec.n_max:
+            from gnm.maxnb import MaxNeighbours
+            batch.maxnb = MaxNeighbours(batch_graph, not self.learn_eps, self.arena().device)   # graphcnn.py:55-81
+        return batch
+
     def forward(self, batch_graph, latent=False):
-        if self.neighbor_pooling_type == "max":
-            return self._forward_max(batch_graph, latent)
-        if not self.training and self.eval_replay and 0 < len(batch_graph) <= self.EVAL_REPLAY_MAX_B:
+        if (not self.training and self.eval_replay and not self._spec.n_max
+                and 0 < len(batch_graph) <= self.EVAL_REPLAY_MAX_B):
             out = self._forward_eval_replay(batch_graph, latent)
             if out is not None:
                 return out
-        batch = self.arena().batch(batch_graph)
-        return self.forward_batch(batch, latent=latent)
+        return self.forward_batch(self._batch_of(batch_graph), latent=latent)
 
     def compute_saliency(self, batch_graph, cls):
         self.eval()
         self.zero_grad()
         assert len(batch_graph) == 1                                           # graphcnn.py:257
-        if self.neighbor_pooling_type == "max":
-            return self._saliency_max(batch_graph, cls)
-        batch = self.arena().batch(batch_graph)
+        batch = self._batch_of(batch_graph)
         X = batch.arena.features(batch).detach().requires_grad_()
         score, _, _ = self._run(batch, X, np.zeros(1, dtype=np.int64), want_disc=False)
         predicting_class = torch.zeros([1, 2], device=X.device)                # two classes hard-coded (:263)
         predicting_class[0, cls] = 1
         score.backward(predicting_class)
-        return X.grad
-
-    # ------------------------------------------------------------------ "max" fallback (plain torch)
-    def _padded_neighbors(self, batch_graph):
-        """graphcnn.py:55-81: padded neighbour list with -1 as the dummy slot."""
-        max_deg = max(g.max_neighbor for g in batch_graph)
-        rows, start = [], 0
-        for g in batch_graph:
-            for j, nb in enumerate(g.neighbors):
-                pad = [x + start for x in nb] + [-1] * (max_deg - len(nb))
-                if not self.learn_eps:
-                    pad.append(j + start)
-                rows.append(pad)
-            start += len(g.g)
-        return torch.LongTensor(rows)
-
-    def _encode_max(self, batch_graph, X):
-        dev = X.device
-        nbr = self._padded_neighbors(batch_graph).to(dev)
-        h, hidden = X, []
-        for l in range(self.num_layers):
-            dummy = torch.min(h, dim=0)[0]                                     # graphcnn.py:137-143
-            pooled = torch.max(torch.cat([h, dummy.reshape(1, -1)])[nbr], dim=1)[0]
-            if self.learn_eps:
-                pooled = pooled + (1 + self.eps[l]) * h
-            h = F.relu(self.batch_norms[l](self.mlps[l](pooled)))
-            hidden.append(h)
-        return hidden
-
-    def _readout_matrix(self, batch_graph, dev):
-        sizes = torch.tensor([len(g.g) for g in batch_graph])
-        seg = torch.repeat_interleave(torch.arange(len(batch_graph)), sizes)
-        val = torch.ones(int(sizes.sum()))
-        if self.graph_pooling_type == "average":
-            val = val / sizes[seg].float()
-        P = torch.zeros(len(batch_graph), int(sizes.sum()))
-        P[seg, torch.arange(int(sizes.sum()))] = val
-        return P.to(dev)
-
-    def _forward_max(self, batch_graph, latent):
-        dev = self.eps.device
-        X = torch.cat([g.node_features for g in batch_graph], 0).to(dev)
-        P = self._readout_matrix(batch_graph, dev)
-        perm = np.random.permutation(len(batch_graph))
-        idx = np.repeat(perm, len(batch_graph[0].node_features))
-        hidden = self._encode_max(batch_graph, X)
-        c_logit, pooled = 0, []
-        for l, h in enumerate(hidden):
-            ph = P @ h
-            c_logit = c_logit + F.dropout(self.linears_prediction[l](ph), self.final_dropout, training=self.training)
-            pooled.append(ph)
-        n_f, g_f = torch.cat(hidden, 1), torch.cat(pooled, 1)
-        d_logit = self.disc(self.sigm(g_f), n_f, n_f[idx, :], None, None)
-        if latent:
-            return g_f.detach().cpu().numpy()
-        return c_logit, d_logit
-
-    def _saliency_max(self, batch_graph, cls):
-        dev = self.eps.device
-        X = torch.cat([g.node_features for g in batch_graph], 0).to(dev).requires_grad_()
-        P = self._readout_matrix(batch_graph, dev)
-        score = 0
-        for l, h in enumerate(self._encode_max(batch_graph, X)):
-            score = score + self.linears_prediction[l](P @ h)
-        onehot = torch.zeros([1, 2], device=dev)
-        onehot[0, cls] = 1
-        score.backward(onehot)
         return X.grad
 
 

@@ -260,6 +260,31 @@ int gnm_head_bwd(const float* dC, int lddc, const float* masks, const float* g_f
                  int ldcs, const float* T, int ldt, int B, int L, int H, int C, const float* const* wp_host,
                  float* const* dwp_host, float* const* dbp_host, float* dph, int lddph, void* stream);
 
+/* ---- neighbor_pooling_type == "max" (csrc/maxpool.hip) ---------------------------------
+ * Replaces __preprocess_neighbors_maxpool + maxpool (graphcnn.py:55-81, 137-143) and the autograd of
+ * torch.max(h_with_dummy[padded_neighbor_list], dim = 1) behind them.  The padded [N, max_deg (+1)] list is not
+ * built: nb_off [N+1] / nb_col are the concatenated graph.neighbors lists (batch-global row ids, the lists' own
+ * order), max_deg the batch maximum (graph.max_neighbor, :59); a row with fewer neighbours gets ONE dummy candidate
+ * (`dummy` [F] = column minimum of h, :140; may be NULL when no row is shorter than max_deg) after them, and self_last = 1 (learn_eps False, :73-74) appends the row
+ * itself.  Selection follows ATen's CPU scan (first maximum wins, a NaN ends the scan); amax [N*F] (optional)
+ * records the selected row per element (-1 = the dummy), which is where the backward sends the gradient.
+ * eps != NULL: out = max + (1 + *eps) * h (graphcnn.py:161).  Returns GNM_ERR_BAD_ARG where torch raises (no
+ * candidate at all: max_deg == 0 without self_last).
+ * gnm_maxpool_colmin: vmin [F] / amin [F] = torch.min(h, dim = 0) values and (first-occurrence) rows; ws_val /
+ * ws_idx hold gnm_maxpool_colmin_blocks(N) * F entries each.
+ * gnm_maxpool_bwd: dh[j] = sum of g[i] over the rows i whose amax is j (t_off [N+1] / t_col: for every row j the
+ * DISTINCT rows i that have j as a candidate, ascending -- include (j, j) when self_last was set) + (1 + *eps) g[j];
+ * iso_rows [n_iso] = rows without neighbours (the only ones that can select the dummy): their gradient goes to row
+ * amin[c].  No atomics: results are bitwise repeatable. */
+int gnm_maxpool_colmin_blocks(int N);
+int gnm_maxpool_colmin(const float* h, int ldh, int N, int F, float* ws_val, int32_t* ws_idx, float* vmin, int32_t* amin,
+                       void* stream);
+int gnm_maxpool_fwd(const float* h, int ldh, const int32_t* nb_off, const int32_t* nb_col, int N, int F, int max_deg,
+                    int self_last, const float* eps, const float* dummy, float* out, int ldo, int32_t* amax, void* stream);
+int gnm_maxpool_bwd(const float* g, int ldg, const int32_t* amax, const int32_t* t_off, const int32_t* t_col, int N, int F,
+                    const float* eps, const int32_t* iso_rows, int n_iso, const int32_t* amin, float* dh, int ldd,
+                    void* stream);
+
 /* ---- train-step tail ----------------------------------------------
  * gnm_loss_ce_bce replaces, in the reference's train() (main.py:16-17, 32-37):
  *     c_loss = CrossEntropyLoss()(c_logit, c_labels)

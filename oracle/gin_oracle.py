@@ -71,6 +71,52 @@ def build_graph_pool(batch, graph_pooling_type):
     return idx, np.asarray(vals, dtype=np.float32), (len(batch), int(start[-1]))
 
 
+def build_padded_neighbors(batch, learn_eps):
+    """graphcnn.py:55-81 -- [N, max_deg (+1)] padded neighbour lists: batch-global ids in graph.neighbors order,
+    -1 in the padding slots (:69), the node itself appended when learn_eps is False (:73-74)."""
+    max_deg = max(int(g.max_neighbor) for g in batch)                         # :59
+    start = start_indices(batch)
+    rows = []
+    for i, g in enumerate(batch):
+        for j in range(len(g.neighbors)):
+            pad = [int(x) + int(start[i]) for x in g.neighbors[j]]            # :67
+            pad.extend([-1] * (max_deg - len(pad)))                          # :69
+            if not learn_eps:
+                pad.append(j + int(start[i]))                                 # :74
+            rows.append(pad)
+    return np.asarray(rows, dtype=np.int64).reshape(len(rows), max_deg + (0 if learn_eps else 1))
+
+
+def maxpool_fwd(h, padded):
+    """graphcnn.py:137-143 -- max over the padded neighbour rows, the padding pointing at a dummy row that holds the
+    column minimum of h.  Returns (pooled, cache); the cache records WHICH candidate torch.max / torch.min select
+    (ATen's CPU kernels keep the first of several equal extrema -- as np.argmax / np.argmin do, NaN included),
+    because that is where autograd sends the gradient."""
+    if padded.shape[1] == 0:
+        raise IndexError("max(): Expected reduction dim 1 to have non-zero size.")    # what torch raises at :142
+    N = h.shape[0]
+    amin = np.argmin(h, axis=0)                                               # :140 torch.min(h, dim = 0)
+    dummy = h[amin, np.arange(h.shape[1])]
+    hd = np.concatenate([h, dummy[None, :]], 0)                               # :141
+    cand = hd[padded]                                                         # :142  [N, D, F] (-1 -> the dummy row)
+    sel = np.argmax(cand, axis=1)                                             # [N, F] position within the padded row
+    pooled = np.take_along_axis(cand, sel[:, None, :], 1)[:, 0, :]
+    src = np.take_along_axis(padded, sel, 1)                                  # selected row id, -1 = dummy
+    return pooled, dict(src=src, amin=amin, N=N)
+
+
+def maxpool_bwd(dpooled, cache):
+    """autograd of maxpool_fwd: each element's gradient goes to the selected row; the dummy's share continues to
+    the row torch.min selected for that column."""
+    N, F_ = cache["N"], dpooled.shape[1]
+    dhd = np.zeros((N + 1, F_), dtype=dpooled.dtype)
+    cols = np.broadcast_to(np.arange(F_), cache["src"].shape)
+    np.add.at(dhd, (np.where(cache["src"] < 0, N, cache["src"]), cols), dpooled)
+    dh = dhd[:N]
+    np.add.at(dh, (cache["amin"], np.arange(F_)), dhd[N])
+    return dh
+
+
 def shuffle_index(batch, perm):
     """graphcnn.py:198-201 -- graph index repeated len(batch[0].node_features)
     times.  NOTE: these are GRAPH indices later used as ROW indices of n_f
@@ -129,22 +175,26 @@ def sigmoid(x):
 class OGraph:
     """Field contract of util.S2VGraph the hot path reads (util.py:9-17)."""
 
-    def __init__(self, n, edge_mat, node_features, label=0):
+    def __init__(self, n, edge_mat, node_features, label=0, neighbors=None, max_neighbor=None):
         self.num_nodes = int(n)                        # len(graph.g)
         self.edge_mat = np.asarray(edge_mat, dtype=np.int64)
         self.node_features = np.asarray(node_features, dtype=np.float32)
         self.label = int(label)
+        # read by the "max" pooling path only (graphcnn.py:59-67)
+        self.neighbors = neighbors
+        self.max_neighbor = (max((len(x) for x in neighbors), default=0) if max_neighbor is None and neighbors is not None
+                             else max_neighbor)
 
 
 # --------------------------------------------------------------------------- #
 # the model                                                                    #
 # --------------------------------------------------------------------------- #
 class OracleGIN:
-    """Restates GIN_InfoMaxReg (graphcnn.py:12-299) for sum/average pooling."""
+    """Restates GIN_InfoMaxReg (graphcnn.py:12-299): sum / average / max neighbour pooling."""
 
     def __init__(self, state, num_layers, num_mlp_layers, learn_eps,
                  graph_pooling_type, neighbor_pooling_type, dtype=np.float32):
-        assert neighbor_pooling_type in ("sum", "average")
+        assert neighbor_pooling_type in ("sum", "average", "max")
         self.L, self.m = int(num_layers), int(num_mlp_layers)
         self.learn_eps = bool(learn_eps)
         self.gpool, self.npool = graph_pooling_type, neighbor_pooling_type
@@ -187,16 +237,23 @@ class OracleGIN:
         # the reference holds 1/n rounded to fp32 (:130); gp_val keeps that rounding in any dtype
         P = coo_to_csr(gp_idx, gp_val, gp_shape, dt)
         idx = shuffle_index(batch, perm)                                      # :198-201
-        a_idx, a_val, a_shape = build_adj_block(batch, self.learn_eps)        # :206
-        A = coo_to_csr(a_idx, a_val, a_shape, dt)
-        deg = np.asarray(A.sum(axis=1)).reshape(-1, 1).astype(dt)             # :157/:181 spmm(A, ones)
+        A = deg = padded = None
+        if self.npool == "max":
+            padded = build_padded_neighbors(batch, self.learn_eps)            # :204
+        else:
+            a_idx, a_val, a_shape = build_adj_block(batch, self.learn_eps)    # :206
+            A = coo_to_csr(a_idx, a_val, a_shape, dt)
+            deg = np.asarray(A.sum(axis=1)).reshape(-1, 1).astype(dt)         # :157/:181 spmm(A, ones)
 
         cache = dict(A=A, P=P, deg=deg, idx=idx, B=B, N=N, layers=[], X=X, training=training)
         h = X
         hidden = []
         for l in range(L):
             lc = {"h_in": h}
-            pooled = A @ h                                                    # :154 / :178
+            if self.npool == "max":
+                pooled, lc["max"] = maxpool_fwd(h, padded)                    # :151 / :175
+            else:
+                pooled = A @ h                                                # :154 / :178
             if self.npool == "average":
                 with np.errstate(divide="ignore", invalid="ignore"):
                     pooled = pooled / deg                                     # :158 / :182 (0/0 -> NaN kept)
@@ -331,8 +388,11 @@ class OracleGIN:
                 # the working dtype, as the HIP kernel does
                 grads["eps"][l] = (dpooled.astype(np.float64) * h_in).sum()
                 d_h = d_h + (1 + self.p["eps"][l]) * dpooled
-            src = dpooled / deg if self.npool == "average" else dpooled
-            d_h = d_h + A.T @ src
+            if self.npool == "max":
+                d_h = d_h + maxpool_bwd(dpooled, lc["max"])
+            else:
+                src = dpooled / deg if self.npool == "average" else dpooled
+                d_h = d_h + A.T @ src
             dh_next = d_h
         if want_dx:
             grads["__dX"] = dh_next

@@ -74,10 +74,13 @@ def corr_graph(seed, n, t, f0, keep_pct=30.0):
     return und, feats, label
 
 
-def make_batch(base_seed, B, n, t, f0):
+def make_batch(base_seed, B, n, t, f0, isolate=None):
+    """isolate = (graph, node): that node loses all its edges (a row of padding only in the "max" pooling list)"""
     graphs, raw = [], []
     for g in range(B):
         und, feats, label = corr_graph(base_seed + g, n, t, f0)
+        if isolate is not None and isolate[0] == g:
+            und = und[(und != isolate[1]).all(1)]
         graphs.append(SynthGraph(n, und, feats, label))
         raw.append((und, feats, label))
     return graphs, raw
@@ -100,10 +103,10 @@ def build_model(seed, L, m, f0, H, C, dropout, learn_eps, gpool, npool):
 
 
 def run_case(tag, model_seed, graph_seed, B, n, t, L, m, f0, H, C, learn_eps, gpool, npool,
-             state_file, row_stride=1, full_disc_grad=True):
+             state_file, row_stride=1, full_disc_grad=True, isolate=None):
     if ONLY is not None and not tag.startswith(ONLY):
         return
-    graphs, raw = make_batch(graph_seed, B, n, t, f0)
+    graphs, raw = make_batch(graph_seed, B, n, t, f0, isolate)
     out = {}
     out["cfg"] = np.array([L, m, f0, H, C, int(learn_eps), B, n], dtype=np.int64)
     out["gpool"] = np.array(gpool)
@@ -130,6 +133,9 @@ def run_case(tag, model_seed, graph_seed, B, n, t, L, m, f0, H, C, learn_eps, gp
         adj = model._GIN_InfoMaxReg__preprocess_neighbors_sumavepool(graphs)
         out["adj_indices"] = adj._indices().numpy().astype(np.int64)
         out["adj_values"] = adj._values().numpy()
+    else:
+        # graphcnn.py:55-81 (graph.neighbors is rebuilt from und_* by the tests exactly as SynthGraph does above)
+        out["padded_neighbors"] = model._GIN_InfoMaxReg__preprocess_neighbors_maxpool(graphs).numpy().astype(np.int64)
     gp = model._GIN_InfoMaxReg__preprocess_graphpool(graphs)
     out["gp_indices"] = gp._indices().numpy().astype(np.int64)
     out["gp_values"] = gp._values().numpy()
@@ -243,6 +249,17 @@ def main():
             for npl in ("sum", "average"):
                 run_case(f"tiny_s1_eps{int(le)}_g{gp}_n{npl}", 1, 700, B=4, n=20, t=40, L=3, m=2, f0=5, H=32, C=2,
                          learn_eps=le, gpool=gp, npool=npl, state_file=s1)
+    # "max" neighbour pooling (graphcnn.py:55-81, 137-143; outside the north_star): both forms, one
+    # batch with a node that has no neighbours (its pooled row is the dummy = column minimum, whose gradient goes to
+    # torch.min's row).  ReLU zeros make equal maxima common from layer 1 on: the gradients pin the tie rule.
+    run_case("tiny_s1_eps1_gsum_nmax", 1, 700, B=4, n=20, t=40, L=3, m=2, f0=5, H=32, C=2,
+             learn_eps=True, gpool="sum", npool="max", state_file=s1)
+    run_case("tiny_s1_eps0_gaverage_nmax", 1, 700, B=4, n=20, t=40, L=3, m=2, f0=5, H=32, C=2,
+             learn_eps=False, gpool="average", npool="max", state_file=s1)
+    run_case("tiny_s1_eps1_gaverage_nmax_iso", 1, 700, B=4, n=20, t=40, L=3, m=2, f0=5, H=32, C=2,
+             learn_eps=True, gpool="average", npool="max", state_file=s1, isolate=(1, 3))
+    run_case("tiny_s1_eps0_gsum_nmax_iso", 1, 700, B=4, n=20, t=40, L=3, m=2, f0=5, H=32, C=2,
+             learn_eps=False, gpool="sum", npool="max", state_file=s1, isolate=(2, 0))
     # single-layer MLP variant (mlp.py:23-25, state_dict key mlps.l.linear.*)
     s2 = os.path.join(HERE, "state_seed2.npz")
     run_case("tiny_s2_mlp1", 2, 900, B=2, n=16, t=32, L=2, m=1, f0=4, H=32, C=2,

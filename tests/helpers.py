@@ -62,6 +62,16 @@ def edge_mat_of(und):
     return np.ascontiguousarray(np.concatenate([e, e[:, ::-1]], 0).T)
 
 
+def neighbors_of(und, n):
+    """graph.neighbors as the golden generator's SynthGraph builds them (util.py:86-90: both ends of every undirected
+    edge, in edge order); read by the "max" neighbour pooling only (graphcnn.py:59-67)."""
+    nb = [[] for _ in range(n)]
+    for i, j in np.asarray(und, dtype=np.int64).reshape(-1, 2):
+        nb[int(i)].append(int(j))
+        nb[int(j)].append(int(i))
+    return nb
+
+
 def rel_err(a, ref, floor=0.0):
     """max|a-ref| / max(max|ref|, floor).  `floor` is an absolute scale for
     quantities that are analytically zero (e.g. the bias gradient of a Linear

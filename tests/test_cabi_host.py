@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import edge_mat_of, golden_cases, load_case
+from helpers import edge_mat_of, golden_cases, load_case, neighbors_of
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -49,6 +49,8 @@ def graphs_of(cfg, d):
         o.edge_mat = torch.from_numpy(edge_mat_of(d[f"und_{g}"]))
         o.node_features = torch.from_numpy(d[f"feat_{g}"])
         o.label = int(d["labels"][g])
+        o.neighbors = neighbors_of(d[f"und_{g}"], cfg["n"])
+        o.max_neighbor = max(len(x) for x in o.neighbors)
         out.append(o)
     return out
 
@@ -62,10 +64,13 @@ def test_csr_arena_matches_reference_coo_bit_exact(case):
     ar = GraphArena("cpu")
     batch = ar.batch(graphs_of(cfg, d))
     assert batch.symmetric and batch.N == cfg["B"] * cfg["n"] and batch.equal_n
-    coo = ar.export_adj_coo(batch, self_loops=not cfg["learn_eps"])
-    ref = d["adj_indices"]
-    canon = lambda a: a[:, np.lexsort((a[1], a[0]))]
-    assert coo.dtype == np.int64 and np.array_equal(canon(coo), canon(ref))
+    if cfg["npool"] == "max":
+        _check_max_neighbour_structure(cfg, d, graphs_of(cfg, d))
+    else:
+        coo = ar.export_adj_coo(batch, self_loops=not cfg["learn_eps"])
+        ref = d["adj_indices"]
+        canon = lambda a: a[:, np.lexsort((a[1], a[0]))]
+        assert coo.dtype == np.int64 and np.array_equal(canon(coo), canon(ref))
     X = ar.features(batch).numpy()
     assert np.array_equal(X, np.concatenate([d[f"feat_{g}"] for g in range(cfg["B"])]))
     # graphs are cached on the object: a second batch adds nothing
@@ -75,6 +80,59 @@ def test_csr_arena_matches_reference_coo_bit_exact(case):
     gs = graphs_of(cfg, d)
     ar.batch(gs); k = len(ar); ar.batch(gs)
     assert len(ar) == k
+
+
+def _check_max_neighbour_structure(cfg, d, graphs):
+    """gnm.maxnb.MaxNeighbours holds exactly the reference's padded neighbour list (graphcnn.py:55-81): expanding its
+    CSR the way the kernel walks it (neighbours, one dummy per short row standing for all its -1 slots, the node
+    itself in the self-loop form) gives the golden LongTensor; the transposed structure lists, for every row, the
+    distinct rows that have it as a candidate."""
+    from gnm.maxnb import MaxNeighbours
+    ref = d["padded_neighbors"]
+    mb = MaxNeighbours(graphs, not cfg["learn_eps"], "cpu")
+    off, col = mb.nb_off.numpy(), mb.nb_col.numpy()
+    assert mb.N == ref.shape[0] and mb.max_deg == ref.shape[1] - (0 if cfg["learn_eps"] else 1)
+    rows = []
+    for i in range(mb.N):
+        r = list(col[off[i]:off[i + 1]])
+        r += [-1] * (mb.max_deg - len(r))
+        if mb.self_last:
+            r.append(i)
+        rows.append(r)
+    assert np.array_equal(np.asarray(rows, dtype=np.int64).reshape(ref.shape), ref)
+    deg = np.diff(off)
+    assert mb.need_dummy == bool((deg < mb.max_deg).any())
+    assert mb.n_iso == int((deg == 0).sum()) and (mb.n_iso == 0 or np.array_equal(mb.iso_rows.numpy(), np.nonzero(deg == 0)[0]))
+    toff, tcol = mb.t_off.numpy(), mb.t_col.numpy()
+    for j in range(mb.N):
+        want = sorted({i for i in range(mb.N) if j in ref[i]})
+        assert list(tcol[toff[j]:toff[j + 1]]) == want
+
+
+def test_max_neighbour_lists_are_cached_and_validated():
+    from gnm.maxnb import MaxNeighbours
+    cfg, state, d = load_case("tiny_s1_eps1_gsum_nmax")
+    gs = graphs_of(cfg, d)
+    MaxNeighbours(gs, False, "cpu")
+    cached = gs[0]._gnm_maxnb[1]
+    MaxNeighbours(gs[:2], True, "cpu")
+    assert gs[0]._gnm_maxnb[1] is cached and set(cached.t) == {False, True}
+    gs[0].neighbors = [list(x) for x in gs[0].neighbors]           # a new list object: re-read
+    MaxNeighbours(gs[:1], False, "cpu")
+    assert gs[0]._gnm_maxnb[1] is not cached
+    gs[1].neighbors[0] = gs[1].neighbors[0] + [cfg["n"]]            # id outside the graph (the reference's gather raises)
+    gs[1].neighbors = list(gs[1].neighbors)
+    with pytest.raises(IndexError):
+        MaxNeighbours(gs[1:2], False, "cpu")
+    gs[2].max_neighbor = 1                                           # shorter than a list: torch.LongTensor(ragged) raises
+    with pytest.raises(ValueError):
+        MaxNeighbours(gs[2:3], False, "cpu")
+    # duplicates and self loops in the lists: one transposed entry per distinct (candidate, row) pair
+    o = G()
+    o.g, o.neighbors, o.max_neighbor = [0, 1, 2], [[1, 1, 0], [0], []], 3
+    mb = MaxNeighbours([o], True, "cpu")
+    assert mb.t_off.tolist() == [0, 2, 4, 5] and mb.t_col.tolist() == [0, 1, 0, 1, 2]
+    assert mb.iso_rows.tolist() == [2] and mb.need_dummy
 
 
 def test_csr_edge_cases():
@@ -134,18 +192,14 @@ def test_no_cpu_fallback():
         m.compute_saliency(graphs_of(cfg, d), 0)              # B must be 1 (graphcnn.py:257)
 
 
-def test_max_pooling_fallback_runs_on_cpu():
-    """neighbor_pooling_type='max' is API-compat only (plain torch); check it runs."""
+def test_max_pooling_has_no_cpu_fallback_either():
+    """neighbor_pooling_type='max' runs through the same HIP engine (csrc/maxpool.hip): on a CPU device it raises."""
+    from gnm._cabi import GnmError
     from models.graphcnn import GIN_InfoMaxReg
-    cfg, state, d = load_case("tiny_s1_eps1_gsum_nsum")
+    cfg, state, d = load_case("tiny_s1_eps1_gsum_nmax")
     gs = graphs_of(cfg, d)
-    for g in gs:
-        em = g.edge_mat.numpy()
-        g.neighbors = [[] for _ in range(cfg["n"])]
-        for i, j in em.T:
-            g.neighbors[int(i)].append(int(j))
-        g.max_neighbor = max(len(x) for x in g.neighbors)
     m = GIN_InfoMaxReg(cfg["L"], cfg["m"], cfg["f0"], cfg["H"], cfg["C"], 0.0, True, "sum", "max", torch.device("cpu"))
-    c, dl = m(gs)
-    assert c.shape == (cfg["B"], 2) and dl.shape == (2 * cfg["B"] * cfg["n"], 1)
-    assert m.compute_saliency(gs[:1], 1).shape == (cfg["n"], cfg["f0"])
+    with pytest.raises(GnmError):
+        m(gs)
+    with pytest.raises(GnmError):
+        m.compute_saliency(gs[:1], 1)

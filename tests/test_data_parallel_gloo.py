@@ -139,33 +139,20 @@ def test_flat_params_keep_module_semantics():
 
 
 def test_autograd_accumulates_into_flat_buffer():
-    """loss.backward() must ADD into the flat gradient views (AccumulateGrad's in-place
-    path), otherwise the all-reduce would see zeros.  Uses the max-pooling torch path,
-    the only one that runs on CPU."""
+    """loss.backward() must ADD into the flat gradient views (AccumulateGrad's in-place path), otherwise the
+    all-reduce would see zeros.  No forward runs on this CPU box (the model has no CPU path): the loss is a function
+    of the parameters themselves, which exercises the same AccumulateGrad nodes."""
     from gnm.parallel import FlatParams
     from models.graphcnn import GIN_InfoMaxReg
-    from helpers import edge_mat_of, load_case
-
-    class G:
-        pass
+    from helpers import load_case
 
     cfg, state, d = load_case("tiny_s1_eps1_gsum_nsum")
-    gs = []
-    for g in range(cfg["B"]):
-        o = G(); o.g = list(range(cfg["n"])); o.node_features = torch.from_numpy(d[f"feat_{g}"]); o.label = 0
-        em = edge_mat_of(d[f"und_{g}"]); o.edge_mat = torch.from_numpy(em)
-        o.neighbors = [[] for _ in range(cfg["n"])]
-        for i, j in em.T:
-            o.neighbors[int(i)].append(int(j))
-        o.max_neighbor = max(len(x) for x in o.neighbors)
-        gs.append(o)
     torch.manual_seed(0)
-    m = GIN_InfoMaxReg(cfg["L"], cfg["m"], cfg["f0"], cfg["H"], cfg["C"], 0.0, True, "sum", "max", torch.device("cpu"))
+    m = GIN_InfoMaxReg(cfg["L"], cfg["m"], cfg["f0"], cfg["H"], cfg["C"], 0.0, True, "sum", "sum", torch.device("cpu"))
     fp = FlatParams(m)
     for step in range(2):                       # second step: views must still be attached
         fp.zero_grad()
-        c, dl = m(gs)
-        (c.sum() + dl.sum()).backward()
+        sum((p * (k + 1.0)).square().sum() for k, p in enumerate(m.parameters())).backward()
         assert fp.flat_grad.abs().sum() > 0
         off = 0
         for p in m.parameters():

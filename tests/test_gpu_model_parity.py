@@ -12,7 +12,7 @@ import json
 import os
 
 from helpers import (RTOL, TRUE_SHAPE_GRAD_RTOL, Calibrated, assert_close, assert_grad_true_shape, edge_mat_of,
-                     golden_cases, grad_floor, load_case, rel_err)
+                     golden_cases, grad_floor, load_case, neighbors_of, rel_err)
 
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
                       "parity_true_shape.json")
@@ -51,8 +51,8 @@ def make_graphs(cfg, d):
         o.edge_mat = torch.from_numpy(edge_mat_of(d[f"und_{g}"]))
         o.node_features = torch.from_numpy(d[f"feat_{g}"])
         o.label = int(d["labels"][g])
-        o.neighbors = None
-        o.max_neighbor = 0
+        o.neighbors = neighbors_of(d[f"und_{g}"], cfg["n"])                 # util.py:86-95
+        o.max_neighbor = max(len(x) for x in o.neighbors)
         out.append(o)
     return out
 
@@ -72,8 +72,8 @@ def oracle_model(cfg, state):
 
 
 def oracle_batch(O, cfg, d):
-    return [O.OGraph(cfg["n"], edge_mat_of(d[f"und_{g}"]), d[f"feat_{g}"], int(d["labels"][g]))
-            for g in range(cfg["B"])]
+    return [O.OGraph(cfg["n"], edge_mat_of(d[f"und_{g}"]), d[f"feat_{g}"], int(d["labels"][g]),
+                     neighbors=neighbors_of(d[f"und_{g}"], cfg["n"])) for g in range(cfg["B"])]
 
 
 def capture_layers(model):
@@ -101,12 +101,21 @@ def test_index_structures_bit_exact(case):
     cfg, state, d = load_case(case)
     model = make_model(cfg, state)
     graphs = make_graphs(cfg, d)
-    batch = model.arena().batch(graphs)
-    coo = model.arena().export_adj_coo(batch, self_loops=not cfg["learn_eps"])
-    ref = d["adj_indices"]
-    assert coo.dtype == np.int64 and coo.shape == ref.shape
-    canon = lambda a: a[:, np.lexsort((a[1], a[0]))]
-    assert np.array_equal(canon(coo), canon(ref))
+    batch = model._batch_of(graphs)
+    if cfg["npool"] == "max":
+        # the device arrays the max-pooling kernels walk, expanded the way they walk them, are the reference's padded
+        # neighbour list (graphcnn.py:55-81); tests/test_cabi_host.py checks the transposed structure too
+        mb, ref = batch.maxnb, d["padded_neighbors"]
+        off, col = mb.nb_off.cpu().numpy(), mb.nb_col.cpu().numpy()
+        rows = [list(col[off[i]:off[i + 1]]) + [-1] * (mb.max_deg - (off[i + 1] - off[i])) + ([i] if mb.self_last else [])
+                for i in range(mb.N)]
+        assert np.array_equal(np.asarray(rows, dtype=np.int64).reshape(ref.shape), ref)
+    else:
+        coo = model.arena().export_adj_coo(batch, self_loops=not cfg["learn_eps"])
+        ref = d["adj_indices"]
+        assert coo.dtype == np.int64 and coo.shape == ref.shape
+        canon = lambda a: a[:, np.lexsort((a[1], a[0]))]
+        assert np.array_equal(canon(coo), canon(ref))
     # readout segments: graph_pool row i covers columns node_off[i]..node_off[i+1]
     gp = d["gp_indices"]
     node_off = batch.node_off.cpu().numpy()
@@ -422,7 +431,8 @@ def test_hipgraph_replay_matches_eager_bitwise():
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("case", ["tiny_s0_eps1_gsum_nsum", "tiny_s1_eps0_gaverage_nsum", "tiny_s2_mlp1"])
+@pytest.mark.parametrize("case", ["tiny_s0_eps1_gsum_nsum", "tiny_s1_eps0_gaverage_nsum", "tiny_s2_mlp1",
+                                  "tiny_s1_eps1_gaverage_nmax_iso"])
 def test_gradient_sink_matches_autograd_accumulation(case):
     """DataParallelGIN's direct mode: kernels write gradients straight into the flat buffer
     (GinSpec.grad_sink) -- bitwise the same values autograd would have accumulated."""

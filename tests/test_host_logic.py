@@ -147,8 +147,10 @@ def test_constructor_rejects_shapes_outside_the_kernels():
         kw.update(bad)
         with pytest.raises(ValueError):
             GIN_InfoMaxReg(kw["num_layers"], 2, kw["input_dim"], kw["hidden_dim"], 2, 0.5, True, "sum", "sum", cpu)
-    # the plain-torch "max" path has no such limits (as the reference)
-    GIN_InfoMaxReg(2, 2, 7, 130, 2, 0.5, True, "sum", "max", cpu)
+    # "max" neighbour pooling runs through the same Linear / BatchNorm kernels: same limits
+    with pytest.raises(ValueError):
+        GIN_InfoMaxReg(2, 2, 7, 130, 2, 0.5, True, "sum", "max", cpu)
+    GIN_InfoMaxReg(2, 2, 7, 64, 2, 0.5, True, "sum", "max", cpu)
 
 
 def test_bench_self_launches_its_ranks():

@@ -9,15 +9,15 @@ import pytest
 
 from helpers import (ORACLE32_FACTOR, RTOL, TRUE_SHAPE_GRAD_RTOL, Calibrated, assert_close, assert_grad_true_shape,
                      edge_mat_of, golden_cases, grad_floor,
-                     load_case)
+                     load_case, neighbors_of)
 from oracle import gin_oracle as O
 
 CASES = golden_cases()
 
 
 def make_batch(cfg, d):
-    return [O.OGraph(cfg["n"], edge_mat_of(d[f"und_{g}"]), d[f"feat_{g}"], int(d["labels"][g]))
-            for g in range(cfg["B"])]
+    return [O.OGraph(cfg["n"], edge_mat_of(d[f"und_{g}"]), d[f"feat_{g}"], int(d["labels"][g]),
+                     neighbors=neighbors_of(d[f"und_{g}"], cfg["n"])) for g in range(cfg["B"])]
 
 
 def make_model(cfg, state, dtype):
@@ -33,10 +33,14 @@ def test_golden_inventory():
 def test_integer_structures_bit_exact(case):
     cfg, state, d = load_case(case)
     batch = make_batch(cfg, d)
-    idx, val, shape = O.build_adj_block(batch, cfg["learn_eps"])
-    assert idx.dtype == np.int64
-    assert np.array_equal(idx, d["adj_indices"])          # same order, same values
-    assert np.array_equal(val, d["adj_values"])
+    if cfg["npool"] == "max":
+        padded = O.build_padded_neighbors(batch, cfg["learn_eps"])
+        assert padded.dtype == np.int64 and np.array_equal(padded, d["padded_neighbors"])
+    else:
+        idx, val, shape = O.build_adj_block(batch, cfg["learn_eps"])
+        assert idx.dtype == np.int64
+        assert np.array_equal(idx, d["adj_indices"])          # same order, same values
+        assert np.array_equal(val, d["adj_values"])
     gidx, gval, gshape = O.build_graph_pool(batch, cfg["gpool"])
     assert np.array_equal(gidx, d["gp_indices"])
     assert np.array_equal(gval, d["gp_values"])            # fp32 1/n bit pattern
