@@ -43,6 +43,8 @@ SIGNATURES = {
     "gnm_maxpool_colmin": (_i, [_p, _i, _i, _i, _p, _p, _p, _p, _p]),
     "gnm_maxpool_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
     "gnm_maxpool_bwd": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
+    "gnm_maxpool_fwd_tiled": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p]),
+    "gnm_maxpool_bwd_tiled": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "gnm_linear_grid": (_i, [_i]),
     "gnm_linear_max_k": (_i, [_i]),
     "gnm_linear_fwd": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _i, _p, _p, _i, _p, _p]),

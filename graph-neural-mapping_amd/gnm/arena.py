@@ -465,16 +465,12 @@ class StaticBatch:
         if (other.B, other.N, other.n_max, other.n_min, other.symmetric, other.dense) != \
                 (b.B, b.N, b.n_max, b.n_min, b.symmetric, b.dense) or other.nnz_max > b.nnz_max:
             raise ValueError("StaticBatch.load: batch shape differs from the captured one")
-        b.node_off.copy_(other.node_off, non_blocking=True)
-        b.rp_off.copy_(other.rp_off, non_blocking=True)
-        b.col_off.copy_(other.col_off, non_blocking=True)
-        b.gids.copy_(other.gids, non_blocking=True)
-        b.feat_base.copy_(other.feat_base, non_blocking=True)
-        b.bits_off.copy_(other.bits_off, non_blocking=True)
+        dst = [b.node_off, b.rp_off, b.col_off, b.gids, b.feat_base, b.bits_off]
+        src = [other.node_off, other.rp_off, other.col_off, other.gids, other.feat_base, other.bits_off]
         if not b.symmetric:
-            b.t_rp_off.copy_(other.t_rp_off, non_blocking=True)
-            b.t_col_off.copy_(other.t_col_off, non_blocking=True)
-            b.t_bits_off.copy_(other.t_bits_off, non_blocking=True)
+            dst += [b.t_rp_off, b.t_col_off, b.t_bits_off]
+            src += [other.t_rp_off, other.t_col_off, other.t_bits_off]
+        torch._foreach_copy_(dst, src, non_blocking=True)      # one launch per dtype instead of one copy per vector
 
 
 class PackedStaticBatch:

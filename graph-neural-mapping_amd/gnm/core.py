@@ -238,9 +238,16 @@ def _max_fwd(batch, h, pooled, F_, eps_ptr):
         raise IndexError("max(): Expected reduction dim 1 to have non-zero size.")     # what torch.max raises (:142)
     amax = torch.empty((N, F_), dtype=torch.int32, device=dev)
     with _timed("maxpool_fwd_F%d" % F_, F=F_, B=batch.B, N=N):
-        check(lib.gnm_maxpool_fwd(h.data_ptr(), h.stride(0), mb.nb_off.data_ptr(), mb.nb_col.data_ptr(), N, F_,
-                                  mb.max_deg, int(mb.self_last), eps_ptr, ptr(dummy), pooled.data_ptr(),
-                                  pooled.stride(0), amax.data_ptr(), _stream()), "gnm_maxpool_fwd")
+        # one workgroup per graph with its rows in LDS when the shape allows, else rows gathered from L2: same bits
+        rc = lib.gnm_maxpool_fwd_tiled(h.data_ptr(), h.stride(0), mb.nb_off.data_ptr(), mb.nb_col.data_ptr(),
+                                       batch.node_off.data_ptr(), batch.B, batch.n_max, F_, mb.max_deg,
+                                       int(mb.self_last), eps_ptr, ptr(dummy), pooled.data_ptr(), pooled.stride(0),
+                                       amax.data_ptr(), _stream())
+        if rc == -2:
+            rc = lib.gnm_maxpool_fwd(h.data_ptr(), h.stride(0), mb.nb_off.data_ptr(), mb.nb_col.data_ptr(), N, F_,
+                                     mb.max_deg, int(mb.self_last), eps_ptr, ptr(dummy), pooled.data_ptr(),
+                                     pooled.stride(0), amax.data_ptr(), _stream())
+        check(rc, "gnm_maxpool_fwd")
     return amax, amin
 
 
@@ -250,9 +257,15 @@ def _max_bwd(batch, dpooled, dh, F_, eps_ptr, aux, hfwd, deps_partial):
     mb = batch.maxnb
     amax, amin = aux
     with _timed("maxpool_bwd_F%d" % F_, F=F_, B=batch.B, N=batch.N):
-        check(lib.gnm_maxpool_bwd(dpooled.data_ptr(), dpooled.stride(0), amax.data_ptr(), mb.t_off.data_ptr(),
-                                  mb.t_col.data_ptr(), batch.N, F_, eps_ptr, ptr(mb.iso_rows), mb.n_iso, ptr(amin),
-                                  dh.data_ptr(), dh.stride(0), _stream()), "gnm_maxpool_bwd")
+        rc = lib.gnm_maxpool_bwd_tiled(dpooled.data_ptr(), dpooled.stride(0), amax.data_ptr(), mb.t_off.data_ptr(),
+                                       mb.t_col.data_ptr(), batch.node_off.data_ptr(), batch.B, batch.n_max, F_,
+                                       eps_ptr, ptr(mb.iso_rows), mb.n_iso, ptr(amin), dh.data_ptr(), dh.stride(0),
+                                       _stream())
+        if rc == -2:
+            rc = lib.gnm_maxpool_bwd(dpooled.data_ptr(), dpooled.stride(0), amax.data_ptr(), mb.t_off.data_ptr(),
+                                     mb.t_col.data_ptr(), batch.N, F_, eps_ptr, ptr(mb.iso_rows), mb.n_iso, ptr(amin),
+                                     dh.data_ptr(), dh.stride(0), _stream())
+        check(rc, "gnm_maxpool_bwd")
     if deps_partial is None:
         return 0
     check(lib.gnm_rowdot_partials(dpooled.data_ptr(), dpooled.stride(0), hfwd.data_ptr(), hfwd.stride(0), batch.N, F_,

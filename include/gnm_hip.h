@@ -275,7 +275,11 @@ int gnm_head_bwd(const float* dC, int lddc, const float* masks, const float* g_f
  * gnm_maxpool_bwd: dh[j] = sum of g[i] over the rows i whose amax is j (t_off [N+1] / t_col: for every row j the
  * DISTINCT rows i that have j as a candidate, ascending -- include (j, j) when self_last was set) + (1 + *eps) g[j];
  * iso_rows [n_iso] = rows without neighbours (the only ones that can select the dummy): their gradient goes to row
- * amin[c].  No atomics: results are bitwise repeatable. */
+ * amin[c].  No atomics: results are bitwise repeatable.
+ * The _tiled forms do the same work with one workgroup per graph and the graph's rows staged in LDS (node_off [B+1]
+ * = first row of each graph, n_max = most rows of one graph): same candidates, same scan order, bitwise the same
+ * results, ~15x faster on 400-node graphs.  They take F = 32 or 64 with 16-byte aligned rows and a tile that fits the
+ * CU's LDS (about 4 F n_max bytes forward, 6 F n_max backward) and return GNM_ERR_UNSUPPORTED otherwise. */
 int gnm_maxpool_colmin_blocks(int N);
 int gnm_maxpool_colmin(const float* h, int ldh, int N, int F, float* ws_val, int32_t* ws_idx, float* vmin, int32_t* amin,
                        void* stream);
@@ -284,6 +288,12 @@ int gnm_maxpool_fwd(const float* h, int ldh, const int32_t* nb_off, const int32_
 int gnm_maxpool_bwd(const float* g, int ldg, const int32_t* amax, const int32_t* t_off, const int32_t* t_col, int N, int F,
                     const float* eps, const int32_t* iso_rows, int n_iso, const int32_t* amin, float* dh, int ldd,
                     void* stream);
+int gnm_maxpool_fwd_tiled(const float* h, int ldh, const int32_t* nb_off, const int32_t* nb_col, const int32_t* node_off,
+                          int B, int n_max, int F, int max_deg, int self_last, const float* eps, const float* dummy,
+                          float* out, int ldo, int32_t* amax, void* stream);
+int gnm_maxpool_bwd_tiled(const float* g, int ldg, const int32_t* amax, const int32_t* t_off, const int32_t* t_col,
+                          const int32_t* node_off, int B, int n_max, int F, const float* eps, const int32_t* iso_rows,
+                          int n_iso, const int32_t* amin, float* dh, int ldd, void* stream);
 
 /* ---- train-step tail ----------------------------------------------
  * gnm_loss_ce_bce replaces, in the reference's train() (main.py:16-17, 32-37):

@@ -124,6 +124,38 @@ def test_maxpool_forward_and_backward_bit_exact(sizes, density, F, kind, iso, du
                               torch.cuda.current_stream().cuda_stream), "maxpool_bwd")
     if kind != "nan":
         assert np.array_equal(dh.cpu().numpy(), want_dh)
+    _check_tiled(graphs, mb, h, 0.37 if learn_eps else None, got, amax, amin, dummy, gd, epsd, dh)
+
+
+def _check_tiled(graphs, mb, h, eps, got, amax, amin, dummy, gd, epsd, dh):
+    """the one-workgroup-per-graph forms (rows in LDS) take F = 32 / 64 and give the bits of the gather-from-L2 forms;
+    other shapes are declined"""
+    from gnm._cabi import lib
+    N, F = h.shape
+    sizes = [len(g.g) for g in graphs]
+    node_off = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=DEV)
+    hd = torch.from_numpy(h).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    out2 = torch.full((N, F + 4), float("inf"), device=DEV)
+    amax2 = torch.full((N, F), -7, dtype=torch.int32, device=DEV)
+    e1 = torch.tensor([eps], dtype=torch.float32, device=DEV) if eps is not None else None
+    rc = lib.gnm_maxpool_fwd_tiled(hd.data_ptr(), F, mb.nb_off.data_ptr(), mb.nb_col.data_ptr(), node_off.data_ptr(),
+                                   len(sizes), max(sizes), F, mb.max_deg, int(mb.self_last),
+                                   e1.data_ptr() if e1 is not None else None,
+                                   dummy.data_ptr() if dummy is not None else None, out2.data_ptr(), F + 4,
+                                   amax2.data_ptr(), st)
+    assert rc == (0 if F in (32, 64) else -2)
+    dh2 = torch.full((N, F), float("nan"), device=DEV)
+    rc2 = lib.gnm_maxpool_bwd_tiled(gd.data_ptr(), F, amax.data_ptr(), mb.t_off.data_ptr(), mb.t_col.data_ptr(),
+                                    node_off.data_ptr(), len(sizes), max(sizes), F,
+                                    epsd.data_ptr() if epsd is not None else None,
+                                    mb.iso_rows.data_ptr() if mb.n_iso else None, mb.n_iso,
+                                    amin.data_ptr() if amin is not None else None, dh2.data_ptr(), F, st)
+    assert rc2 == rc
+    if rc == 0:
+        assert np.array_equal(out2[:, :F].cpu().numpy(), got, equal_nan=True) and torch.isinf(out2[:, F:]).all()
+        assert torch.equal(amax2, amax)
+        assert torch.equal(dh2, dh) or bool(torch.isnan(dh).any())
 
 
 def test_maxpool_refusals_and_empty():
@@ -167,6 +199,23 @@ def test_maxpool_true_shape_properties_and_determinism():
     got, amax, amin, dummy = _run_fwd(mb, h, None)
     got2, amax2, _, _ = _run_fwd(mb, h, None)
     assert np.array_equal(got, got2) and torch.equal(amax, amax2)
+    # ... and the tiled form (what the model runs at this shape) gives the same bits, forward and backward
+    node_off = torch.arange(65, dtype=torch.int32, device=DEV) * 400
+    hd, st0 = torch.from_numpy(h).to(DEV), torch.cuda.current_stream().cuda_stream
+    out3, amax3 = torch.empty(N, F, device=DEV), torch.empty(N, F, dtype=torch.int32, device=DEV)
+    check(lib.gnm_maxpool_fwd_tiled(hd.data_ptr(), F, mb.nb_off.data_ptr(), mb.nb_col.data_ptr(), node_off.data_ptr(), 64,
+                                    400, F, mb.max_deg, 1, None, dummy.data_ptr() if dummy is not None else None,
+                                    out3.data_ptr(), F, amax3.data_ptr(), st0), "fwd_tiled")
+    assert np.array_equal(out3.cpu().numpy(), got) and torch.equal(amax3, amax)
+    gr = torch.randn(N, F, device=DEV)
+    d1, d2 = torch.empty(N, F, device=DEV), torch.empty(N, F, device=DEV)
+    epsd = torch.tensor([0.25], device=DEV)
+    check(lib.gnm_maxpool_bwd(gr.data_ptr(), F, amax.data_ptr(), mb.t_off.data_ptr(), mb.t_col.data_ptr(), N, F,
+                              epsd.data_ptr(), None, 0, None, d1.data_ptr(), F, st0), "bwd")
+    check(lib.gnm_maxpool_bwd_tiled(gr.data_ptr(), F, amax.data_ptr(), mb.t_off.data_ptr(), mb.t_col.data_ptr(),
+                                    node_off.data_ptr(), 64, 400, F, epsd.data_ptr(), None, 0, None, d2.data_ptr(), F, st0),
+          "bwd_tiled")
+    assert torch.equal(d1, d2)
     am = amax.cpu().numpy()
     assert (am >= 0).all()                                                     # every row has its self candidate
     assert np.array_equal(got, h[am, np.arange(F)[None, :]])                   # attained by the selected row
