@@ -182,9 +182,11 @@ def main():
         ref = []
         for k in range(2):
             em = pool[k].edge_mat.to(dev)
-            A = torch.zeros(400, 400, device=dev, dtype=torch.float64)
+            nk = int(b1.node_off_host[k + 1] - b1.node_off_host[k])
+            assert int(em.max()) < nk
+            A = torch.zeros(nk, nk, device=dev, dtype=torch.float64)
             A.index_put_((em[0], em[1]), torch.ones(em.shape[1], device=dev, dtype=torch.float64), accumulate=True)
-            xs = x1[400 * k:400 * (k + 1)].double()
+            xs = x1[int(b1.node_off_host[k]):int(b1.node_off_host[k + 1])].double()
             ref.append(A @ xs + xs)
         ref = torch.cat(ref)
         err = (y1.double() - ref).abs().max().item() / ref.abs().max().item()
