@@ -30,9 +30,9 @@ class CapturedTrainStep:
         keep = [t for t in model.state_dict().values()] + list(preserve)
         snapshot = [t.clone() for t in keep]
         dev = template_batch.node_off.device
-        self.static = StaticBatch(template_batch)
         B = template_batch.B
-        self.labels = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.static = StaticBatch(template_batch, extra_int64=B)      # the labels ride in the same buffer
+        self.labels = self.static.extra
         self.perm = torch.arange(B, dtype=torch.int32, device=dev)
         self.loss = None
         self._zero = zero_grad or (lambda: model.zero_grad(set_to_none=False))
@@ -84,8 +84,7 @@ class CapturedTrainStep:
         if self._arena_buffers() != self._arena_ptrs:
             raise RuntimeError("the graph arena was re-allocated after this step was captured (graphs were added): "
                                "add every graph before building CapturedTrainStep / FusedTrainStep, or build a new one")
-        self.static.load(batch)
-        self.labels.copy_(labels, non_blocking=True)
+        self.static.load(batch, extra=labels.to(torch.int64))
         self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
         self.graph.replay()
         return self.loss
