@@ -325,8 +325,10 @@ def main():
         kernel_timer = core.KernelTimer(None if args.time_all_kernels else
                                         ("agg_fwd_F%d" % H, "agg_bwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
     # the HIP events of the roofline kernels cost ~2 % of a step when recorded on every launch: they are recorded on
-    # every 4th timed step (still inside the timed region, >= 5 steps x 4-9 launches at the default --steps 20)
-    timer_every = 1 if args.time_all_kernels or args.steps < 8 else 4
+    # every 4th timed step.  In the hybrid mode the steps that carry them are EAGER steps, which a busy host stretches
+    # (measured: 1.5-2.7 % on the run's average at every 4th): every 10th there (still inside the timed region: 2 steps
+    # x 4 / 4 / 9 launches of the three roofline kernels at the default --steps 20)
+    timer_every = 1 if args.time_all_kernels or args.steps < 8 else (10 if hybrid and args.steps >= 20 else 4)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

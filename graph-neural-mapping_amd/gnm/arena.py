@@ -98,6 +98,7 @@ class GraphArena:
         self._token = object()
         self._agg0 = {}
         self._minus_one = None
+        self._arange = {}           # {n: arange(n) on the device}: one launch less per feature gather
 
     def __len__(self):
         return len(self.n)
@@ -339,7 +340,10 @@ class GraphArena:
     def _feature_rows(self, batch):
         if batch.equal_n:
             base = batch.feat_base
-            return (base[:, None] + torch.arange(batch.n_max, device=self.device)[None, :]).reshape(-1)
+            ar = self._arange.get(batch.n_max)
+            if ar is None:
+                ar = self._arange[batch.n_max] = torch.arange(batch.n_max, device=self.device)[None, :]
+            return (base[:, None] + ar).reshape(-1)
         tb = self._tables()
         ns = tb["n"][batch.gids]
         base = torch.repeat_interleave(batch.feat_base, ns)
