@@ -17,7 +17,8 @@ Prints one JSON line (rank 0).  Extra objects:
                 previous layer's BatchNorm+ReLU+readout on the tile load): algorithmic bytes
                 (396,804 B per graph-layer) / mean launch duration from
                 HIP events on the launch stream, against 8 TB/s.
-  roofline_mlp  the fp32-MFMA Linear(64,64) forward launches against 157.3 TFLOP/s.
+  roofline_mlp  the Linear(64,64) forward launches: bytes in + out against 8 TB/s (the split-precision bf16 kernel
+                is HBM-bound; with GNM_LIN_NO_SPLIT=1 the fp32-MFMA kernel against 157.3 TFLOP/s).
   cpu_baseline  oracle/gin_oracle.py (numpy/scipy port of the reference's CPU path,
                 pinned to the reference's golden vectors) timed on this host on config
                 C1 (B = 32 of the same graphs), rank 0, N = 1 only.
@@ -478,10 +479,22 @@ def main():
                 c, ms, meta = summ[key]
                 fl = 2.0 * meta["N"] * H * H
                 tf = fl / (ms * 1e-3) / 1e12
-                roof_mlp = {"bound": "mfma", "kernel": "gnm_lin_stream_kernel<64,2> (Linear %dx%d fwd)" % (H, H),
-                            "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                            "mean_launch_ms": ms, "launches_timed": c,
-                            "hbm_GBs": (meta["N"] * H * 4 * 2) / (ms * 1e-3) / 1e9}
+                gbs = (meta["N"] * H * 4 * 2) / (ms * 1e-3) / 1e9
+                split = (H == 64 and os.environ.get("GNM_LIN_GENERIC") is None and
+                         not any(os.environ.get(k, "0") not in ("", "0") for k in ("GNM_LIN_NO_SPLIT", "GNM_LIN_NO_STREAM")))
+                if split:
+                    # csrc/linear.hip gnm_lin_split_kernel: both operands as three exact bf16 planes, six bf16 MFMA
+                    # terms per product -- the matrix pipe is no longer what the waves queue for; HBM is
+                    roof_mlp = {"bound": "hbm", "kernel": "gnm_lin_split_kernel<2> (Linear %dx%d fwd, 3 x 3 bf16 planes, "
+                                                          "6 MFMA terms)" % (H, H),
+                                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "mean_launch_ms": ms, "launches_timed": c, "hbm_GBs": gbs,
+                                "fp32_equivalent_TFLOPs": tf, "bf16_mfma_TFLOPs": 6 * tf,
+                                "bf16_mfma_frac_of_2500": 6 * tf / 2500.0}
+                else:
+                    roof_mlp = {"bound": "mfma", "kernel": "gnm_lin_stream_kernel<64,2> (Linear %dx%d fwd)" % (H, H),
+                                "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                                "mean_launch_ms": ms, "launches_timed": c, "hbm_GBs": gbs}
         out["roofline"] = roof
         out["roofline_mlp"] = roof_mlp
         if world == 1 and not args.no_cpu_baseline and not sparse and default_cfg:

@@ -38,6 +38,7 @@ struct LinArgs {
     int w_kmajor;            // 0: W[h*ldw+k] (torch Linear weight);  1: W[k*ldw+h]
     int pro_relu;
     unsigned long long* stamps;   // tuning builds only (gnm_debug_set_lin_stamps): [block][4 waves][64] s_memtime
+    int stat_rows;           // gnm_lin_split_kernel: rows of stats_partial = groups of four waves that take tiles
 };
 
 #ifdef GNM_LIN_TUNING
@@ -646,6 +647,270 @@ static int launch_lin_stream(const LinArgs& a, int grid, hipStream_t s) {
     return GNM_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// Split-precision variant of the streaming kernel for K = 64, H = 64 (every hidden Linear of the headline model).
+// The fp32 matrix instruction (v_mfma_f32_32x32x2_f32, 64 FLOP/clk per SIMD) kept a wave in its product for 41 % of
+// its life with three waves per SIMD -- the matrix pipe was the resource the waves queued for, not HBM.  Here both
+// operands are split by truncation into three bf16 planes each (x = x1 + x2 + x3 EXACTLY: 8 + 8 + 8 mantissa bits) and
+// the product runs as six bf16 matrix instructions per 16 k (x1w1, x1w2, x2w1, x2w2, x1w3, x3w1; 16x the fp32 rate):
+// every partial product is exact in the fp32 accumulator, the three dropped terms are below 2^-24 of |x||w| each --
+// the size of the accumulator's own rounding -- and the instruction count falls from 64 x 64 to 48 x 32 cycles per tile.
+// One 768-thread workgroup per CU (12 waves share one 24 KB image of the weight planes; three 256-thread workgroups
+// with a copy each do not fit the LDS); its waves form three groups of four that write three rows of statistics
+// partials, so the launch produces exactly the gnm_linear_grid(N) rows the BatchNorm finalize expects.
+// ---------------------------------------------------------------------------------
+typedef __bf16 lin_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void lin_split3(const float f, unsigned& a1, unsigned& a2, unsigned& a3) {
+    a1 = __float_as_uint(f) & 0xFFFF0000u;
+    const float r1 = f - __uint_as_float(a1);
+    a2 = __float_as_uint(r1) & 0xFFFF0000u;
+    a3 = __float_as_uint(r1 - __uint_as_float(a2));        // <= 8 significant bits left: its top half is all of it
+}
+// (top 16 bits of hi_word) : (top 16 bits of lo_word)
+__device__ __forceinline__ unsigned lin_bf16_pair(unsigned lo_word, unsigned hi_word) {
+    return __builtin_amdgcn_perm(hi_word, lo_word, 0x07060302u);
+}
+// eight consecutive-k floats -> the three bf16x8 operands
+__device__ __forceinline__ void lin_split8(const float* f, u32x4& p1, u32x4& p2, u32x4& p3) {
+    unsigned a1[8], a2[8], a3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) lin_split3(f[j], a1[j], a2[j], a3[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        p1[j] = lin_bf16_pair(a1[2 * j], a1[2 * j + 1]);
+        p2[j] = lin_bf16_pair(a2[2 * j], a2[2 * j + 1]);
+        p3[j] = lin_bf16_pair(a3[2 * j], a3[2 * j + 1]);
+    }
+}
+
+static constexpr int kSplitWaves = 12;
+
+template <int HT>
+__global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const LinArgs p) {
+    constexpr int KC = 64, NW = kSplitWaves, NT = NW * 64;
+    constexpr int HP = HT * 32;
+    constexpr int XS = (KC > HP ? KC : HP) + 4;
+    constexpr int C4 = KC / 4;
+    constexpr int KH = KC / 2;
+    constexpr int NLD = (32 * C4) / 64;
+    constexpr int RSTEP = 64 / C4;
+    constexpr int O4 = HP / 4;
+    constexpr int NST = (32 * O4) / 64;
+    constexpr int WSTEP = 64 / O4;
+    constexpr int E = 4 * HT * 64;                // operand entries (16 B) per weight plane: [m][c][lane]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* Wp = reinterpret_cast<u32x4*>(smem);                               // [3][E]
+    float* Xs_all = reinterpret_cast<float*>(smem + (size_t)3 * E * 16);      // [NW][32][XS]; first the fp32 weight image
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    float* Xs = Xs_all + wave * 32 * XS;
+
+    const int c4 = lane % C4;
+    const int lrow0 = lane / C4;
+    float bias_r[HT];
+#pragma unroll
+    for (int c = 0; c < HT; ++c) bias_r[c] = p.bias ? p.bias[32 * c + i] : 0.f;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool pro = p.pro_scale != nullptr;
+    if (pro) {
+        sc = *reinterpret_cast<const float4*>(p.pro_scale + 4 * c4);
+        sh = *reinterpret_cast<const float4*>(p.pro_shift + 4 * c4);
+    }
+    // waves are numbered across the launch; groups of four own one row of statistics partials, exactly the tile ->
+    // row map of the 4-wave kernels; waves past the last row (a grid that is not a multiple of 3) take no tiles
+    const int gw = blockIdx.x * NW + wave;
+    const int ntiles = (gw < 4 * p.stat_rows) ? (p.N + 31) / 32 : 0;
+    const int tstride = 4 * p.stat_rows;
+    const int in_voff = (lrow0 * p.ldx + 4 * c4) * 4;
+    const int in_step = RSTEP * p.ldx * 4;
+    const int out_voff = ((lane / O4) * p.ldz + 4 * (lane % O4)) * 4;
+    const int out_step = WSTEP * p.ldz * 4;
+
+    u32x4 raw[NLD];
+    auto load_tile = [&](int tile) {
+        const long long row0 = (long long)tile * 32;
+        const __amdgpu_buffer_rsrc_t rs = gnm_tile_rsrc(p.X + row0 * p.ldx, min((long long)p.N - row0, 32LL), p.ldx, KC);
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, j * in_step, 0);
+    };
+    int t = gw;
+    load_tile(t);
+
+    // weight -> fp32 image Wt[k][h] in the staging region, then -> the three bf16 operand planes
+    float* Wt = Xs_all;
+    const bool w_vec = (p.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0;
+    auto load_w4 = [&](const float* src) -> float4 {
+        if (w_vec) return *reinterpret_cast<const float4*>(src);
+        return make_float4(src[0], src[1], src[2], src[3]);
+    };
+    if (p.w_kmajor) {
+        for (int idx = tid; idx < KC * O4; idx += NT) {
+            const int k = idx / O4, h4 = idx - k * O4;
+            *reinterpret_cast<float4*>(Wt + k * HP + 4 * h4) = load_w4(p.W + (size_t)k * p.ldw + 4 * h4);
+        }
+    } else {
+        for (int idx = tid; idx < C4 * HP; idx += NT) {
+            const int k4 = idx / HP, hh = idx - k4 * HP;
+            const float4 w = load_w4(p.W + (size_t)hh * p.ldw + 4 * k4);
+            Wt[(4 * k4 + 0) * HP + hh] = w.x;
+            Wt[(4 * k4 + 1) * HP + hh] = w.y;
+            Wt[(4 * k4 + 2) * HP + hh] = w.z;
+            Wt[(4 * k4 + 3) * HP + hh] = w.w;
+        }
+    }
+    __syncthreads();
+    // entry (m, c, lane = 32 kg + n): W[k = 8 m + 32 kg + 0..7][h = 32 c + n] -- the k numbering the A fragments use
+    for (int e = tid; e < E; e += NT) {
+        const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % HT, m = e / (64 * HT);
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = Wt[(8 * m + 32 * kg + j) * HP + 32 * c + n];
+        u32x4 p1, p2, p3;
+        lin_split8(f, p1, p2, p3);
+        Wp[e] = p1; Wp[E + e] = p2; Wp[2 * E + e] = p3;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): nothing from the preamble is pending inside the tile loop
+    __syncthreads();
+
+    double st1[HT], st2[HT];
+#pragma unroll
+    for (int c = 0; c < HT; ++c) { st1[c] = 0.0; st2[c] = 0.0; }
+    auto do_tile = [&](int t) {
+        const int r0 = t * 32;
+        f32x16 acc[HT];
+#pragma unroll
+        for (int c = 0; c < HT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            float4 v = __builtin_bit_cast(float4, raw[j]);
+            if (pro) {
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (p.pro_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            *reinterpret_cast<float4*>(Xs + (lrow0 + j * RSTEP) * XS + 4 * c4) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // row i, k = 32 h + 0..31 -> four A fragments (m: k = 8 m + 32 h + 0..7) x three planes
+        u32x4 A1[4], A2[4], A3[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 v0 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m);
+            const float4 v1 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            lin_split8(f, A1[m], A2[m], A3[m]);
+        }
+        load_tile(t + tstride);                   // past the last tile: an empty descriptor, no memory traffic
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const lin_bf16x8 a1 = __builtin_bit_cast(lin_bf16x8, A1[m]), a2 = __builtin_bit_cast(lin_bf16x8, A2[m]),
+                             a3 = __builtin_bit_cast(lin_bf16x8, A3[m]);
+#pragma unroll
+            for (int c = 0; c < HT; ++c) {
+                const int e = (m * HT + c) * 64 + lane;
+                const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wp[e]), b2 = __builtin_bit_cast(lin_bf16x8, Wp[E + e]),
+                                 b3 = __builtin_bit_cast(lin_bf16x8, Wp[2 * E + e]);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[c], 0, 0, 0);      // small terms first
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[c], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // A fragments are in registers before the staging image is reused
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float z = acc[c][r] + bias_r[c];
+                Xs[lrow * XS + 32 * c + i] = z;
+                if (r0 + lrow < p.N) {
+                    s1 += z;
+                    s2 += z * z;
+                }
+            }
+            st1[c] += (double)s1;
+            st2[c] += (double)s2;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, min(p.N - r0, 32), p.ldz, HP);
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            const int idx = lane + 64 * st;
+            const int row = idx / O4, oc = idx - row * O4;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(Xs + row * XS + 4 * oc);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rz, out_voff + st * out_step, 0, 0);     // (row step in the vector offset: see above)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    if (t < ntiles) {
+        do_tile(t);
+        for (t += tstride; t < ntiles; t += tstride) do_tile(t);
+    }
+
+    if (p.stats_partial) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem);   // [NW waves][2][HP]
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            const double a1 = st1[c] + __shfl_xor(st1[c], 32, 64);
+            const double a2 = st2[c] + __shfl_xor(st2[c], 32, 64);
+            if (h == 0) {
+                red[(wave * 2 + 0) * HP + 32 * c + i] = a1;
+                red[(wave * 2 + 1) * HP + 32 * c + i] = a2;
+            }
+        }
+        __syncthreads();
+        // three rows of partials per workgroup (waves 0-3, 4-7, 8-11): gnm_linear_grid(N) rows per launch, as always
+        for (int idx = tid; idx < 3 * 2 * HP; idx += NT) {
+            const int grp = idx / (2 * HP), rest = idx - grp * 2 * HP;
+            const int which = rest / HP, col = rest - which * HP;
+            const int row = blockIdx.x * 3 + grp;
+            if (row >= p.stat_rows) continue;
+            double s = 0.0;
+            for (int w = 4 * grp; w < 4 * grp + 4; ++w) s += red[(w * 2 + which) * HP + col];
+            p.stats_partial[((size_t)row * 2 + which) * p.H + col] = s;
+        }
+    }
+}
+
+template <int HT>
+static int launch_lin_split(const LinArgs& a0, int grid, hipStream_t s) {
+    LinArgs a = a0;
+    a.stat_rows = grid;
+    const int grid3 = (grid + 2) / 3;
+    constexpr int HP = HT * 32;
+    constexpr int XS = (64 > HP ? 64 : HP) + 4;
+    const size_t lds = (size_t)3 * 4 * HT * 64 * 16 + (size_t)kSplitWaves * 32 * XS * 4;
+    if (lds > (size_t)kLdsBudget) return GNM_ERR_UNSUPPORTED;
+    GNM_ALLOW_FULL_LDS((&gnm_lin_split_kernel<HT>));
+    hipLaunchKernelGGL((gnm_lin_split_kernel<HT>), dim3(grid3), dim3(kSplitWaves * 64), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+static bool lin_no_split() {
+    static const bool v = gnm_env_int("GNM_LIN_NO_SPLIT", 0) != 0;     // A/B knob: keep the fp32 matrix instruction
+    return v;
+}
+
 static size_t lin_lds_bytes(int K, int KC, int HT) {
     const int KP = ((K + KC - 1) / KC) * KC;
     size_t b = (size_t)KP * HT * 32 * 4 + (size_t)4 * 32 * (KC + 4) * 4;
@@ -711,6 +976,11 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
         int rc = GNM_ERR_UNSUPPORTED;
         // one chunk per row and descriptors that fit 32-bit offsets: the streaming kernel
         const bool small_ld = (long long)ldx * 32 * 4 < (1LL << 31) && (long long)ldz * 32 * 4 < (1LL << 31);
+        // K = H = 64: the split-precision kernel
+        if (K == 64 && HT == 2 && small_ld && !lin_no_stream() && !lin_no_split()) {
+            rc = launch_lin_split<2>(a, grid, s);
+            if (rc != GNM_ERR_UNSUPPORTED) return rc;
+        }
         if ((K == 32 || K == 64) && small_ld && !lin_no_stream()) {
 #define GNM_LINS_CASE(KC_, HT_) if (K == KC_ && HT == HT_) rc = launch_lin_stream<KC_, HT_>(a, grid, s);
             GNM_LINS_CASE(32, 1) GNM_LINS_CASE(32, 2) GNM_LINS_CASE(32, 3) GNM_LINS_CASE(32, 4)
