@@ -914,6 +914,11 @@ static bool lin_no_split() {
     return v;
 #endif
 }
+// the fused backward kernels' products alone (GNM_LIN_NO_SPLIT covers them too)
+static bool linbwd_no_split() {
+    static const bool v = gnm_env_int("GNM_LINBWD_NO_SPLIT", 0) != 0;
+    return v || lin_no_split();
+}
 
 static size_t lin_lds_bytes(int K, int KC, int HT) {
     const int KP = ((K + KC - 1) / KC) * KC;
@@ -1370,8 +1375,9 @@ struct LbArgs {
 // (the second Linear of every MLP) -- the ReLU mask and the BatchNorm sums are then taken from the X values the
 // weight-gradient product already holds in registers: the wgrad contraction index is permuted so that a lane's X
 // rows are its dX accumulator rows, and no second pass over that array is made.
-template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false>
+template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false, bool SPLITD = false>
 __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbArgs p) {   // 2 waves/SIMD: <= 256 registers
+    static_assert(!SPLITD || (SAMEZ && KT == 2 && HT == 2), "SPLITD: the SAMEZ K = H = 64 form only");
     static_assert(!NARROW || (KT == 1 && !STATS), "narrow K: one tile, no lower BatchNorm");
     static_assert(!SAMEZ || STATS, "SAMEZ is a STATS variant");
     constexpr int KP = KT * 32, HP = HT * 32;
@@ -1382,17 +1388,33 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
     constexpr int KH = HP / 2;                    // dgrad MFMA steps (contraction over H)
     constexpr int O4 = KP / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // SPLITD (the SAMEZ K = H = 64 form): the dgrad product runs on the bf16 matrix pipe with dZ and W split into three
+    // exact bf16 planes each (see gnm_lin_split_kernel); the weight image is then the three operand planes (24 KB)
+    constexpr int EW = 4 * KT * 64;
     float* Wt = reinterpret_cast<float*>(smem);                   // [HP][KP]: W itself (contraction index first)
-    float* Xs_all = Wt + (size_t)HP * KP;                         // [4][32][XS]
+    u32x4* Wp = reinterpret_cast<u32x4*>(smem);                   // SPLITD: [3][EW] operand entries instead
+    float* Xs_all = SPLITD ? reinterpret_cast<float*>(smem + (size_t)3 * EW * 16) : Wt + (size_t)HP * KP;   // [4][32][XS]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     float* Xs = Xs_all + wave * 32 * XS;
     GNM_LSTAMP(0)
-    for (int idx = tid; idx < HP * KP; idx += 256) {
-        const int hh = idx / KP, k = idx - hh * KP;
-        Wt[idx] = (!NARROW || k < p.K) ? p.W[(size_t)hh * p.ldw + k] : 0.f;
+    if constexpr (SPLITD) {
+        for (int e = tid; e < EW; e += 256) {
+            const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % KT, m = e / (64 * KT);
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = p.W[(size_t)(8 * m + 32 * kg + j) * p.ldw + 32 * c + n];
+            u32x4 p1, p2, p3;
+            lin_split8(f, p1, p2, p3);
+            Wp[e] = p1; Wp[EW + e] = p2; Wp[2 * EW + e] = p3;
+        }
+    } else {
+        for (int idx = tid; idx < HP * KP; idx += 256) {
+            const int hh = idx / KP, k = idx - hh * KP;
+            Wt[idx] = (!NARROW || k < p.K) ? p.W[(size_t)hh * p.ldw + k] : 0.f;
+        }
     }
     __syncthreads();
     GNM_LSTAMP(1)
@@ -1491,7 +1513,37 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
         GNM_LSTAMP(3 + 5 * min(tk, 11))
         // ---- dX = dZ W ------------------------------------------------------------------
         f32x16 dacc[KT];
-        if (p.dA) {
+        if constexpr (SPLITD) {
+            if (p.dA) {
+#pragma unroll
+                for (int c = 0; c < KT; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dacc[c][r] = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m);
+                    const float4 v1 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m + 4);
+                    const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    u32x4 A1, A2, A3;
+                    lin_split8(f, A1, A2, A3);
+                    const lin_bf16x8 x1 = __builtin_bit_cast(lin_bf16x8, A1), x2 = __builtin_bit_cast(lin_bf16x8, A2),
+                                     x3 = __builtin_bit_cast(lin_bf16x8, A3);
+#pragma unroll
+                    for (int c = 0; c < KT; ++c) {
+                        const int e = (m * KT + c) * 64 + lane;
+                        const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wp[e]),
+                                         b2 = __builtin_bit_cast(lin_bf16x8, Wp[EW + e]),
+                                         b3 = __builtin_bit_cast(lin_bf16x8, Wp[2 * EW + e]);
+                        dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b3, dacc[c], 0, 0, 0);
+                        dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, b1, dacc[c], 0, 0, 0);
+                        dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b2, dacc[c], 0, 0, 0);
+                        dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b2, dacc[c], 0, 0, 0);
+                        dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b1, dacc[c], 0, 0, 0);
+                        dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b1, dacc[c], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (p.dA) {
             float a[KH];
 #pragma unroll
             for (int j = 0; j < KH / 4; ++j) {
@@ -2215,15 +2267,15 @@ static int launch_lb_pipe(const LbArgs& a, int grid, hipStream_t s) {
     return GNM_OK;
 }
 
-template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false>
+template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false, bool SPLITD = false>
 static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
-    size_t lds = (size_t)HP * KP * 4 + (size_t)4 * 32 * XS * 4;
+    size_t lds = (SPLITD ? (size_t)3 * 4 * KT * 64 * 16 : (size_t)HP * KP * 4) + (size_t)4 * 32 * XS * 4;
     const size_t dump = ((size_t)4 * HT * KT * 1024 + (size_t)4 * HT * 64) * 4;
     if (dump > lds) lds = dump;
-    GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ>));
-    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ>), dim3(grid), dim3(256), lds, s, a);
+    GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ, SPLITD>));
+    hipLaunchKernelGGL((gnm_linear_bwd_fused_kernel<KT, HT, STATS, NARROW, SAMEZ, SPLITD>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
@@ -2284,7 +2336,7 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
         if (KT == 1 && HT == 1) rc = launch_lb_pipe<1, 1>(a, grid, s);
         if (KT == 2 && HT == 1) rc = launch_lb_pipe<2, 1>(a, grid, s);
         if (KT == 1 && HT == 2) rc = launch_lb_pipe<1, 2>(a, grid, s);
-        if (KT == 2 && HT == 2) rc = lin_no_split() ? launch_lb_pipe<2, 2>(a, grid, s) : launch_lb_pipe3(a, grid, s);
+        if (KT == 2 && HT == 2) rc = linbwd_no_split() ? launch_lb_pipe<2, 2>(a, grid, s) : launch_lb_pipe3(a, grid, s);
     }
     if (narrow && HT == 1) rc = launch_lb<1, 1, false, true>(a, grid, s);
     if (narrow && HT == 2) rc = launch_lb<1, 2, false, true>(a, grid, s);
@@ -2295,7 +2347,8 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     const bool samez = sZ && sZ == X && ldsz == ldx && s_scale == pro_scale && s_shift == pro_shift && pro_relu &&
                        !linbwd_no_samez();
     if (!pipe && KT == 2 && HT == 2)
-        rc = samez ? launch_lb<2, 2, true, false, true>(a, grid, s)
+        rc = samez ? (linbwd_no_split() ? launch_lb<2, 2, true, false, true>(a, grid, s)
+                                        : launch_lb<2, 2, true, false, true, true>(a, grid, s))
                    : (sZ ? launch_lb<2, 2, true>(a, grid, s) : launch_lb<2, 2, false>(a, grid, s));
     if (rc != GNM_OK) return rc;
     if (!dW) return GNM_OK;      // deferred: the partials stay in `workspace` for gnm_reduce_partials_multi
