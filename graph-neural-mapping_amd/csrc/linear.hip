@@ -1764,8 +1764,13 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
 // the shared template and as a SAMEZ flavour of this kernel with the request behind the wgrad MFMAs: 31-150 spills),
 // and any restructuring of that kernel's body moved its register allocation.
 // ---------------------------------------------------------------------------------
-template <int KT, int HT>
+// SPLITD (K = H = 64): the dgrad product on the bf16 matrix pipe, dZ and W as three exact bf16 planes each (see
+// gnm_lin_split_kernel).  wgrad keeps the fp32 instruction: on the bf16 pipe as well (a separate kernel, batch row as
+// the contraction index, dZ columns from the LDS image and X rows from global split per tile) it was 12 % faster than
+// the fp32 kernel stand-alone but spilled 18 dwords, and in the step it came out 0.3 % behind this form.
+template <int KT, int HT, bool SPLITD = false>
 __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArgs p) {
+    static_assert(!SPLITD || (KT == 2 && HT == 2), "SPLITD: K = H = 64 only");
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
     constexpr int H4 = HP / 4;
@@ -1774,17 +1779,31 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
     constexpr int KH = HP / 2;
     constexpr int O4 = KP / 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int EW = 4 * KT * 64;
     float* Wt = reinterpret_cast<float*>(smem);                   // [HP][KP]
-    float* Xs_all = Wt + (size_t)HP * KP;                         // [4][32][XS]
+    u32x4* Wp = reinterpret_cast<u32x4*>(smem);                   // SPLITD: [3][EW] bf16 operand entries of W instead
+    float* Xs_all = SPLITD ? reinterpret_cast<float*>(smem + (size_t)3 * EW * 16) : Wt + (size_t)HP * KP;   // [4][32][XS]
     float* coef = Xs_all + 4 * 32 * XS;                           // [5][HP]: mean, rstd, cA, m1, m2 of the BatchNorm
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     float* Xs = Xs_all + wave * 32 * XS;
-    for (int idx = tid; idx < HP * KP; idx += 256) {
-        const int hh = idx / KP, k = idx - hh * KP;
-        Wt[idx] = p.W[(size_t)hh * p.ldw + k];
+    if constexpr (SPLITD) {
+        for (int e = tid; e < EW; e += 256) {
+            const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % KT, m = e / (64 * KT);
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = p.W[(size_t)(8 * m + 32 * kg + j) * p.ldw + 32 * c + n];
+            u32x4 p1, p2, p3;
+            lin_split8(f, p1, p2, p3);
+            Wp[e] = p1; Wp[EW + e] = p2; Wp[2 * EW + e] = p3;
+        }
+    } else {
+        for (int idx = tid; idx < HP * KP; idx += 256) {
+            const int hh = idx / KP, k = idx - hh * KP;
+            Wt[idx] = p.W[(size_t)hh * p.ldw + k];
+        }
     }
     // the BatchNorm-backward coefficient vectors live in LDS and are read per tile (5 ds_read_b128: they count on
     // lgkmcnt, so re-reading them costs no place in the in-order vector-memory queue and no registers across the tile)
@@ -1870,7 +1889,34 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
         __builtin_amdgcn_sched_barrier(0);
         // ---- dX = dZ W ------------------------------------------------------------------
         f32x16 dacc[KT];
-        {
+        if constexpr (SPLITD) {
+#pragma unroll
+            for (int c = 0; c < KT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[c][r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 v0 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m);
+                const float4 v1 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m + 4);
+                const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                u32x4 A1, A2, A3;
+                lin_split8(f, A1, A2, A3);
+                const lin_bf16x8 x1 = __builtin_bit_cast(lin_bf16x8, A1), x2 = __builtin_bit_cast(lin_bf16x8, A2),
+                                 x3 = __builtin_bit_cast(lin_bf16x8, A3);
+#pragma unroll
+                for (int c = 0; c < KT; ++c) {
+                    const int e = (m * KT + c) * 64 + lane;
+                    const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wp[e]), b2 = __builtin_bit_cast(lin_bf16x8, Wp[EW + e]),
+                                     b3 = __builtin_bit_cast(lin_bf16x8, Wp[2 * EW + e]);
+                    dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b3, dacc[c], 0, 0, 0);
+                    dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, b1, dacc[c], 0, 0, 0);
+                    dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b2, dacc[c], 0, 0, 0);
+                    dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b2, dacc[c], 0, 0, 0);
+                    dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b1, dacc[c], 0, 0, 0);
+                    dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b1, dacc[c], 0, 0, 0);
+                }
+            }
+        } else {
             float a[KH];
 #pragma unroll
             for (int j = 0; j < KH / 4; ++j) {
@@ -1984,285 +2030,15 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
     }
 }
 
-// ---------------------------------------------------------------------------------
-// gnm_linear_bwd_pipe_kernel<2, 2> with both products on the bf16 matrix pipe (see gnm_lin_split_kernel): dZ, W and
-// f(X) are split by truncation into three exact bf16 planes and every product is six bf16 terms -- 96 x 32 instead of
-// 128 x 64 matrix-pipe cycles per tile.  dgrad has the forward's operand layout (dZ row i, contraction over the 64
-// columns; W planes in LDS); for wgrad the batch row is the contraction index: a lane holds, for its column, the eight
-// consecutive rows 16 q + 8 h + 0..7 of dZ (LDS, conflict-free column reads) and of X (global, 128-byte row pieces),
-// two 16-row steps per tile.  Accumulator layouts, the dX stores, the cross-tile G / Z request and the final
-// workgroup combine are the fp32 kernel's.
-// ---------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe3_kernel(const LbArgs p) {
-    constexpr int KT = 2, HT = 2;
-    constexpr int KP = KT * 32, HP = HT * 32;
-    constexpr int XS = (KP > HP ? KP : HP) + 4;
-    constexpr int H4 = HP / 4;
-    constexpr int NLD = (32 * H4) / 64;
-    constexpr int RSTEP = 64 / H4;
-    constexpr int KH = HP / 2;
-    constexpr int O4 = KP / 4;
-    constexpr int E = 4 * KT * 64;                // operand entries (16 B) per weight plane: [m][c][lane]
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4* Wp = reinterpret_cast<u32x4*>(smem);                               // [3][E]
-    float* Xs_all = reinterpret_cast<float*>(smem + (size_t)3 * E * 16);      // [4][32][XS]
-    float* coef = Xs_all + 4 * 32 * XS;                                       // [5][HP]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, h = lane >> 5;
-    float* Xs = Xs_all + wave * 32 * XS;
-    // dgrad B operand: entry (m, c, lane = 32 kg + n) = W[h' = 8 m + 32 kg + 0..7][k = 32 c + n], three planes
-    for (int e = tid; e < E; e += 256) {
-        const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % KT, m = e / (64 * KT);
-        float f[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = p.W[(size_t)(8 * m + 32 * kg + j) * p.ldw + 32 * c + n];
-        u32x4 p1, p2, p3;
-        lin_split8(f, p1, p2, p3);
-        Wp[e] = p1; Wp[E + e] = p2; Wp[2 * E + e] = p3;
-    }
-    for (int idx = tid; idx < HP; idx += 256) {
-        coef[idx] = p.mean[idx]; coef[HP + idx] = p.rstd[idx]; coef[2 * HP + idx] = p.cA[idx];
-        coef[3 * HP + idx] = p.m1[idx]; coef[4 * HP + idx] = p.m2[idx];
-    }
-    const int c4 = lane % H4, lrow0 = lane / H4;
-    float psc[KT], psh[KT];
-#pragma unroll
-    for (int b = 0; b < KT; ++b) {
-        psc[b] = p.pro_scale ? p.pro_scale[32 * b + i] : 1.f;
-        psh[b] = p.pro_scale ? p.pro_shift[32 * b + i] : 0.f;
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): nothing from the preamble is pending inside the tile loop
-    __syncthreads();
-    f32x16 wacc[HT][KT];
-#pragma unroll
-    for (int a = 0; a < HT; ++a)
-#pragma unroll
-        for (int b = 0; b < KT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) wacc[a][b][r] = 0.f;
-    float dbacc[HT];
-#pragma unroll
-    for (int a = 0; a < HT; ++a) dbacc[a] = 0.f;
-
-    const int ntiles = (p.N + 31) / 32;
-    const int tstride = gridDim.x * 4;
-    const int gz_voff_g = (lrow0 * p.ldg + 4 * c4) * 4, gz_step_g = RSTEP * p.ldg * 4;
-    const int gz_voff_z = (lrow0 * p.ldz + 4 * c4) * 4, gz_step_z = RSTEP * p.ldz * 4;
-    const int x_voff = (8 * h * p.ldx + i) * 4;                   // X[r0 + 16 q + 8 h + j][32 b + i]
-    const int out_voff = ((lane / O4) * p.lda + 4 * (lane % O4)) * 4, out_step = (64 / O4) * p.lda * 4;
-    const float* dxbase = p.dA ? p.dA : p.G;
-
-    u32x4 g4[NLD], z4[NLD];
-    auto load_z = [&](int tile) {
-        const long long row0 = (long long)tile * 32;
-        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + row0 * p.ldz, min((long long)p.N - row0, 32LL), p.ldz, HP);
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) z4[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, gz_voff_z, j * gz_step_z, 0);
-    };
-    auto load_g = [&](int tile) {
-        const long long row0 = (long long)tile * 32;
-        const __amdgpu_buffer_rsrc_t rg = gnm_tile_rsrc(p.G + row0 * p.ldg, min((long long)p.N - row0, 32LL), p.ldg, HP);
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) g4[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, gz_voff_g, j * gz_step_g, 0);
-    };
-    auto load_gz = [&](int tile) { load_z(tile); load_g(tile); };
-#define GNM_MFMA6(acc_, a1_, a2_, a3_, b1_, b2_, b3_)                                   \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b3_, acc_, 0, 0, 0);            \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b1_, acc_, 0, 0, 0);            \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b2_, acc_, 0, 0, 0);            \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b2_, acc_, 0, 0, 0);            \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b1_, acc_, 0, 0, 0);            \
-    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc_, 0, 0, 0);
-    auto do_tile = [&](int t, int t_next) {
-        const int r0 = t * 32;
-        const int rows = min(p.N - r0, 32);
-        const float4 mu = *reinterpret_cast<const float4*>(coef + 4 * c4);
-        const float4 rs = *reinterpret_cast<const float4*>(coef + HP + 4 * c4);
-        const float4 ca = *reinterpret_cast<const float4*>(coef + 2 * HP + 4 * c4);
-        const float4 a1 = *reinterpret_cast<const float4*>(coef + 3 * HP + 4 * c4);
-        const float4 a2 = *reinterpret_cast<const float4*>(coef + 4 * HP + 4 * c4);
-#pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int lrow = lrow0 + j * RSTEP;
-            const float4 gj = __builtin_bit_cast(float4, g4[j]), zj = __builtin_bit_cast(float4, z4[j]);
-            float4 d;
-            d.x = ca.x * (gj.x - a1.x - (zj.x - mu.x) * rs.x * a2.x);
-            d.y = ca.y * (gj.y - a1.y - (zj.y - mu.y) * rs.y * a2.y);
-            d.z = ca.z * (gj.z - a1.z - (zj.z - mu.z) * rs.z * a2.z);
-            d.w = ca.w * (gj.w - a1.w - (zj.w - mu.w) * rs.w * a2.w);
-            if (lrow >= rows) d = make_float4(0.f, 0.f, 0.f, 0.f);
-            *reinterpret_cast<float4*>(Xs + lrow * XS + 4 * c4) = d;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // f(X) operands of the wgrad product: in flight during the dgrad MFMAs (clipped rows read 0; their dZ is 0)
-        float xv[2][8][KT];
-        const __amdgpu_buffer_rsrc_t rx = gnm_tile_rsrc(p.X + (size_t)r0 * p.ldx, rows, p.ldx, KP);
-        auto load_x = [&](int q) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int b = 0; b < KT; ++b)
-                    xv[q][j][b] = __uint_as_float(
-                        __builtin_amdgcn_raw_buffer_load_b32(rx, x_voff, ((16 * q + j) * p.ldx + 32 * b) * 4, 0));
-        };
-        load_x(0);
-        load_x(1);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- dX = dZ W ------------------------------------------------------------------
-        f32x16 dacc[KT];
-#pragma unroll
-        for (int c = 0; c < KT; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dacc[c][r] = 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float4 v0 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m);
-            const float4 v1 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m + 4);
-            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            u32x4 A1, A2, A3;
-            lin_split8(f, A1, A2, A3);
-            const lin_bf16x8 x1 = __builtin_bit_cast(lin_bf16x8, A1), x2 = __builtin_bit_cast(lin_bf16x8, A2),
-                             x3 = __builtin_bit_cast(lin_bf16x8, A3);
-#pragma unroll
-            for (int c = 0; c < KT; ++c) {
-                const int e = (m * KT + c) * 64 + lane;
-                const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wp[e]), b2 = __builtin_bit_cast(lin_bf16x8, Wp[E + e]),
-                                 b3 = __builtin_bit_cast(lin_bf16x8, Wp[2 * E + e]);
-                GNM_MFMA6(dacc[c], x1, x2, x3, b1, b2, b3)
-            }
-        }
-        load_gz(t_next);                          // past the wave's last tile: empty descriptors, no traffic
-        // ---- dW += dZ^T f(X), db += column sums of dZ: two steps of 16 rows ----------------
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            // (the X planes of both column blocks stay live across the two dZ column blocks; the dZ planes are
-            // formed per block: 36 operand registers instead of 48 -- the kernel sits at the 256-register line)
-            lin_bf16x8 x1[KT], x2[KT], x3[KT];
-#pragma unroll
-            for (int b = 0; b < KT; ++b) {
-                float f[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float x = xv[q][j][b];
-                    if (p.pro_scale) {
-                        x = x * psc[b] + psh[b];
-                        if (p.pro_relu) x = fmaxf(x, 0.f);
-                    }
-                    f[j] = x;
-                }
-                u32x4 P1, P2, P3;
-                lin_split8(f, P1, P2, P3);
-                x1[b] = __builtin_bit_cast(lin_bf16x8, P1); x2[b] = __builtin_bit_cast(lin_bf16x8, P2);
-                x3[b] = __builtin_bit_cast(lin_bf16x8, P3);
-            }
-#pragma unroll
-            for (int a = 0; a < HT; ++a) {
-                float f[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = Xs[(16 * q + 8 * h + j) * XS + 32 * a + i];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dbacc[a] += f[j];
-                u32x4 P1, P2, P3;
-                lin_split8(f, P1, P2, P3);
-                const lin_bf16x8 d1 = __builtin_bit_cast(lin_bf16x8, P1), d2 = __builtin_bit_cast(lin_bf16x8, P2),
-                                 d3 = __builtin_bit_cast(lin_bf16x8, P3);
-#pragma unroll
-                for (int b = 0; b < KT; ++b) { GNM_MFMA6(wacc[a][b], d1, d2, d3, x1[b], x2[b], x3[b]) }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();          // everyone is done reading the dZ image
-#pragma unroll
-        for (int c = 0; c < KT; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Xs[((r & 3) + 8 * (r >> 2) + 4 * h) * XS + 32 * c + i] = dacc[c][r];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
-            const __amdgpu_buffer_rsrc_t rd = gnm_tile_rsrc(dxbase + (p.dA ? (size_t)r0 * p.lda : 0), p.dA ? rows : 0, p.lda, KP);
-#pragma unroll
-            for (int st = 0; st < (32 * O4) / 64; ++st) {
-                const int idx = lane + 64 * st;
-                const int row = idx / O4, oc = idx - row * O4;
-                const u32x4 v = *reinterpret_cast<const u32x4*>(Xs + row * XS + 4 * oc);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rd, out_voff + st * out_step, 0, 0);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
-#undef GNM_MFMA6
-    {
-        int t = blockIdx.x * 4 + wave;
-        load_gz(t);
-        if (t < ntiles) {
-            do_tile(t, t + tstride);                  // peeled
-            for (t += tstride; t < ntiles; t += tstride) do_tile(t, t + tstride);
-        }
-    }
-
-    // ---- combine the 4 waves' dW / db in a fixed order: one partial per block (as in the fp32 kernels) ----
-    __syncthreads();
-    constexpr int TILE = 16 * 64;
-    float* dump = reinterpret_cast<float*>(smem);
-    float* mine = dump + (size_t)wave * HT * KT * TILE;
-#pragma unroll
-    for (int a = 0; a < HT; ++a)
-#pragma unroll
-        for (int b = 0; b < KT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mine[(a * KT + b) * TILE + r * 64 + lane] = wacc[a][b][r];
-    float* dbdump = dump + (size_t)4 * HT * KT * TILE;
-#pragma unroll
-    for (int a = 0; a < HT; ++a) dbdump[(wave * HT + a) * 64 + lane] = dbacc[a];
-    __syncthreads();
-    float* out = p.partial + (size_t)blockIdx.x * ((size_t)p.H * p.K + p.H);
-    for (int idx = tid; idx < HT * KT * TILE; idx += 256) {
-        const int ab = idx / TILE;
-        const int rl = idx - ab * TILE;
-        const int r = rl >> 6, ln = rl & 63;
-        const int a = ab / KT, b = ab - a * KT;
-        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
-        const int col = 32 * b + (ln & 31);
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) sum += dump[(size_t)w * HT * KT * TILE + idx];
-        out[(size_t)row * p.K + col] = sum;
-    }
-    for (int idx = tid; idx < HT * 32; idx += 256) {
-        const int a = idx >> 5, ii = idx & 31;
-        float sum = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) sum += dbdump[(w * HT + a) * 64 + ii] + dbdump[(w * HT + a) * 64 + 32 + ii];
-        out[(size_t)p.H * p.K + 32 * a + ii] = sum;
-    }
-}
-
-static int launch_lb_pipe3(const LbArgs& a, int grid, hipStream_t s) {
-    constexpr int KT = 2, HT = 2, XS = 68;
-    size_t lds = (size_t)3 * 4 * KT * 64 * 16 + (size_t)4 * 32 * XS * 4 + (size_t)5 * HT * 32 * 4;
-    const size_t dump = ((size_t)4 * HT * KT * 1024 + (size_t)4 * HT * 64) * 4;
-    if (dump > lds) lds = dump;
-    GNM_ALLOW_FULL_LDS(&gnm_linear_bwd_pipe3_kernel);
-    hipLaunchKernelGGL(gnm_linear_bwd_pipe3_kernel, dim3(grid), dim3(256), lds, s, a);
-    GNM_CHECK_LAUNCH();
-    return GNM_OK;
-}
-
-template <int KT, int HT>
+template <int KT, int HT, bool SPLITD = false>
 static int launch_lb_pipe(const LbArgs& a, int grid, hipStream_t s) {
     constexpr int KP = KT * 32, HP = HT * 32;
     constexpr int XS = (KP > HP ? KP : HP) + 4;
-    size_t lds = (size_t)HP * KP * 4 + (size_t)4 * 32 * XS * 4 + (size_t)5 * HP * 4;
+    size_t lds = (SPLITD ? (size_t)3 * 4 * KT * 64 * 16 : (size_t)HP * KP * 4) + (size_t)4 * 32 * XS * 4 + (size_t)5 * HP * 4;
     const size_t dump = ((size_t)4 * HT * KT * 1024 + (size_t)4 * HT * 64) * 4;
     if (dump > lds) lds = dump;
-    GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_pipe_kernel<KT, HT>));
-    hipLaunchKernelGGL((gnm_linear_bwd_pipe_kernel<KT, HT>), dim3(grid), dim3(256), lds, s, a);
+    GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_pipe_kernel<KT, HT, SPLITD>));
+    hipLaunchKernelGGL((gnm_linear_bwd_pipe_kernel<KT, HT, SPLITD>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
@@ -2336,7 +2112,7 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
         if (KT == 1 && HT == 1) rc = launch_lb_pipe<1, 1>(a, grid, s);
         if (KT == 2 && HT == 1) rc = launch_lb_pipe<2, 1>(a, grid, s);
         if (KT == 1 && HT == 2) rc = launch_lb_pipe<1, 2>(a, grid, s);
-        if (KT == 2 && HT == 2) rc = linbwd_no_split() ? launch_lb_pipe<2, 2>(a, grid, s) : launch_lb_pipe3(a, grid, s);
+        if (KT == 2 && HT == 2) rc = linbwd_no_split() ? launch_lb_pipe<2, 2>(a, grid, s) : launch_lb_pipe<2, 2, true>(a, grid, s);
     }
     if (narrow && HT == 1) rc = launch_lb<1, 1, false, true>(a, grid, s);
     if (narrow && HT == 2) rc = launch_lb<1, 2, false, true>(a, grid, s);
