@@ -8,7 +8,9 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-KERNELS = ["gnm_lin_stream_kernel<64, 2>", "gnm_linear_bwd_pipe_kernel<2, 2>", "gnm_linear_bwd_fused_kernel<2, 2, true, false, true>",
+KERNELS = ["gnm_lin_split_kernel<2>", "gnm_lin_stream_kernel<64, 2>", "gnm_linear_bwd_pipe_kernel<2, 2, true>",
+           "gnm_linear_bwd_pipe_kernel<2, 2, false>", "gnm_linear_bwd_fused_kernel<2, 2, true, false, true, true>",
+           "gnm_linear_bwd_fused_kernel<2, 2, true, false, true, false>",
            "gnm_aggm_kernel<false, false, false>", "gnm_aggm_kernel<true, false, false>", "gnm_aggm_kernel<false, false, true>",
            "gnm_disc_score_kernel<16>", "gnm_disc_du_kernel"]
 vals = {}
