@@ -273,6 +273,48 @@ def test_linear_forward_stats_and_grads(N, K, H, pro, w_off):
     assert_close(db.cpu().numpy(), dZ.astype(np.float64).sum(0), rtol=TOL, what="bias grad")
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_split_precision_products_are_fp32_accurate(wide):
+    """K = H = 64 Linears run on the bf16 matrix pipe with both operands split into three exact bf16 planes and six of
+    the nine partial products kept (csrc/linear.hip gnm_lin_split_kernel, SPLITD backward forms).  The claim is that
+    this is an fp32-accurate product: element by element the error against fp64 must stay below 1e-6 x sum_k |x_k||w_k|
+    -- a sequential fp32 dot product of length 64 is only guaranteed 64 x 6e-8 = 3.8e-6 of it -- also for operands
+    whose magnitudes span many binades (`wide`: the dropped terms are relative to each product, not to the largest)."""
+    from gnm import core
+    from gnm._cabi import check, lib
+    N, K, H = 4096 + 17, 64, 64
+    rng = np.random.default_rng(21)
+    scale = (lambda shape: np.exp2(rng.integers(-12, 13, shape)).astype(np.float32)) if wide else (lambda shape: np.float32(1))
+    X = (rng.standard_normal((N, K)) * scale((N, K))).astype(np.float32)
+    W = (rng.standard_normal((H, K)) / 8 * scale((H, K))).astype(np.float32)
+    b = rng.standard_normal(H).astype(np.float32)
+    Xd, Wd, bd = (torch.from_numpy(a).to(DEV) for a in (X, W, b))
+    Z = torch.empty(N, H, device=DEV)
+    core._linear(Xd, Wd, 0, bd, Z, N, K, H, None, None)
+    X64, W64 = X.astype(np.float64), W.astype(np.float64)
+    ref = X64 @ W64.T + b
+    bound = np.abs(X64) @ np.abs(W64).T + np.abs(b)
+    err = np.abs(Z.cpu().numpy() - ref) / bound
+    print("split-precision forward: max error %.2e of sum |x||w| (wide = %s)" % (err.max(), wide))
+    assert err.max() < 1e-6
+    # dX of the fused backward (no-statistics form: BatchNorm-backward coefficients chosen so that dZ = G exactly)
+    G = (rng.standard_normal((N, H)) * scale((N, H))).astype(np.float32)
+    Gd = torch.from_numpy(G).to(DEV)
+    zeros, ones = torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
+    dA, dW, db = torch.empty(N, K, device=DEV), torch.empty(H, K, device=DEV), torch.empty(H, device=DEV)
+    ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, H, K)), device=DEV)
+    check(lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Gd.data_ptr(), H, zeros.data_ptr(), ones.data_ptr(), ones.data_ptr(),
+                                   zeros.data_ptr(), zeros.data_ptr(), Xd.data_ptr(), K, None, None, 0, Wd.data_ptr(), K,
+                                   dA.data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, K, H, None, 0, None,
+                                   None, None, None, None, _stream()), "linear_bwd_fused")
+    G64 = G.astype(np.float64)
+    e2 = np.abs(dA.cpu().numpy() - G64 @ W64) / (np.abs(G64) @ np.abs(W64))
+    print("split-precision dgrad: max error %.2e of sum |g||w|" % e2.max())
+    assert e2.max() < 1e-6
+    e3 = np.abs(dW.cpu().numpy() - G64.T @ X64) / (np.abs(G64).T @ np.abs(X64))
+    assert e3.max() < 2e-5            # (wgrad: fp32 instruction, 4,113 rows accumulated in fp32 partials)
+
+
 @pytest.mark.parametrize("N,K,H", [(1000, 64, 64), (33, 64, 64), (4099, 32, 64), (257, 64, 32), (700, 32, 32),
                                    (1000, 7, 64), (97, 5, 32), (4099, 31, 64), (40, 1, 64)])   # K < 32: narrow variant
 @pytest.mark.parametrize("pro,want_dx", [(True, True), (False, True), (True, False)])
