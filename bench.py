@@ -166,7 +166,8 @@ def main():
                          "step, which is launched eagerly so that HIP events can bracket the roofline kernels INSIDE the "
                          "timed region.  An all-eager step costs ~2 ms of host time against ~3 ms of GPU time: on a box "
                          "whose host is busy it is host-bound (4.1 ms measured once), replay is not.  off: all eager")
-    ap.add_argument("--neighbor-pooling", default="sum", choices=["sum", "average"])
+    ap.add_argument("--neighbor-pooling", default="sum", choices=["sum", "average", "max"],
+                    help="max: outside the north_star (csrc/maxpool.hip), eager launches only, no roofline object")
     ap.add_argument("--graph-pooling", default="sum", choices=["sum", "average"])
     ap.add_argument("--keep-pct", type=float, default=30.0,
                     help="dense-FC graphs: percent of the correlation matrix kept as edges (30 = the reference's "
@@ -226,6 +227,9 @@ def main():
     sparse = args.config == "c4"
     B = args.batch or ((1024 if world == 1 else 512) if not sparse else 256)
     pool_n = args.pool or (4096 if not sparse else 512)
+    if args.neighbor_pooling == "max":      # Python neighbour lists per graph (as the reference holds them): keep it small
+        B = args.batch or 256
+        pool_n = args.pool or B
     n, f0, H, L, C = (1000 if sparse else 400), 7, (128 if sparse else args.hidden), args.layers, 2
 
     t_gen = time.perf_counter()
@@ -256,6 +260,15 @@ def main():
         bt = arena.batch_from_gids(gids_all[sel])
         batches.append((bt, labels_all[torch.as_tensor(sel, device=dev)]))
     N = batches[0][0].N
+    if args.neighbor_pooling == "max":
+        # the neighbour lists the reference's max pooling reads (graphcnn.py:55-81); device arrays per batch, untimed
+        from gnm.maxnb import MaxNeighbours
+        for g in pool:
+            g.build_neighbors()
+        rng2 = np.random.default_rng(1234 + rank)
+        for bt, _ in batches:
+            sel = rng2.permutation(pool_n)[:B] if pool_n >= B else rng2.integers(0, pool_n, B)
+            bt.maxnb = MaxNeighbours([pool[i] for i in sel], args.no_learn_eps, dev)
     d_labels = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev)   # main.py:32, sized by node count
 
     if args.torch_loss:
@@ -267,7 +280,7 @@ def main():
         def loss_fn(c_logit, d_logit, lab):        # the same two losses, one fused pass (gnm_loss_ce_bce)
             return infomax_loss(c_logit, d_logit, lab, 0.05)[0]
 
-    use_graph = args.graph in ("on", "auto") and not args.sync_bn
+    use_graph = args.graph in ("on", "auto") and not args.sync_bn and args.neighbor_pooling != "max"
     # N = 1, auto: replayed steps with an eager step (HIP events on the roofline kernels) every `timer_every`
     hybrid = args.graph == "auto" and world == 1 and not args.no_kernel_timer
     captured = None

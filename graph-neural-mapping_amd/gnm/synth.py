@@ -15,7 +15,8 @@ import torch
 class SynthGraph:
     """S2VGraph-shaped object (util.py:9-17): g, label, edge_mat, node_features."""
 
-    __slots__ = ("g", "label", "edge_mat", "node_features", "neighbors", "max_neighbor", "node_tags", "_gnm_cache")
+    __slots__ = ("g", "label", "edge_mat", "node_features", "neighbors", "max_neighbor", "node_tags", "_gnm_cache",
+                 "_gnm_maxnb")
 
     def __init__(self, n, und_edges, feats, label):
         self.g = range(n)                                   # only len(graph.g) is read
@@ -27,6 +28,21 @@ class SynthGraph:
         self.max_neighbor = 0
         self.node_tags = None
         self._gnm_cache = None
+        self._gnm_maxnb = None
+
+    def build_neighbors(self):
+        """graph.neighbors / max_neighbor as util.py:86-95 fills them (read by "max" neighbour pooling only): both ends of
+        every undirected edge in edge order -- here from edge_mat, whose first half lists (i, j) and second half (j, i)"""
+        em = self.edge_mat.numpy()
+        n = len(self.g)
+        half = em.shape[1] // 2
+        src = np.stack([em[0, :half], em[1, :half]], 1).reshape(-1)       # i0, j0, i1, j1, ...
+        dst = np.stack([em[1, :half], em[0, :half]], 1).reshape(-1)
+        order = np.argsort(src, kind="stable")
+        cnt = np.bincount(src, minlength=n)
+        self.neighbors = [x.tolist() for x in np.split(dst[order], np.cumsum(cnt)[:-1])]
+        self.max_neighbor = int(cnt.max()) if n else 0
+        return self
 
 
 def dense_fc_graph(g, n=400, t=256, f0=7, keep_pct=30.0):

@@ -24,4 +24,6 @@ run --batch 32 --graph on
 run --agg0-cache
 run --graph off
 GNM_DENSE_FILL=2 run --graph off
+run --batch 256 --pool 256 --graph off
+run --batch 256 --pool 256 --graph off --neighbor-pooling max
 cat $out
