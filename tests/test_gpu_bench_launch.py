@@ -25,3 +25,21 @@ def test_bench_two_ranks_without_a_launcher():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 64 and out["config"]["graphs_per_gpu"] == 32
     assert out["value"] > 0 and out["ms_per_step"] < 200, out["ms_per_step"]     # round 1: 279-404 ms through gloo
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [["--neighbor-pooling", "max"], ["--config", "c4", "--batch", "8", "--pool", "8"],
+                                   ["--graph", "off"], ["--no-learn-eps", "--graph-pooling", "average"]])
+def test_bench_other_configurations_print_one_line(extra):
+    """the non-default bench configurations (DESIGN.md section 6's matrix) keep working: one JSON line, a finite loss"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    if "--batch" not in extra:
+        cmd += ["--batch", "16", "--pool", "16"]
+    r = subprocess.run(cmd + extra, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
+    assert out["final_loss"] == out["final_loss"] and abs(out["final_loss"]) < 1e6      # finite
