@@ -39,6 +39,7 @@ struct LinArgs {
     int pro_relu;
     unsigned long long* stamps;   // tuning builds only (gnm_debug_set_lin_stamps): [block][4 waves][64] s_memtime
     int stat_rows;           // gnm_lin_split_kernel: rows of stats_partial = groups of four waves that take tiles
+    int stage_out;           // gnm_lin_kernel: the launch reserved LDS for the output staging image
 };
 
 #ifdef GNM_LIN_TUNING
@@ -68,6 +69,11 @@ __global__ void __launch_bounds__(256) gnm_lin_kernel(const LinArgs p) {
     const int i = lane & 31;
     const int h = lane >> 5;
     float* Xs = Xs_all + wave * 32 * XS;
+    // output staging (aligned full-width outputs): the tile leaves as 16-byte row-contiguous stores -- 1 KiB per
+    // wave-instruction instead of 128-byte column pieces; the input layer's Linear (K = F0) is all output traffic
+    constexpr int OS = HP + 4, O4 = HP / 4;
+    float* Os = Xs_all + 4 * 32 * XS + wave * 32 * OS;
+    const bool vec_out = p.stage_out && p.H == HP && (p.ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(p.Z) & 15) == 0;
 
     // ---- stage W^T (k-major, zero padded) --------------------------------------
     if (p.w_kmajor) {
@@ -171,16 +177,32 @@ __global__ void __launch_bounds__(256) gnm_lin_kernel(const LinArgs p) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int grow = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int grow = r0 + lrow;
                 const float z = acc[c][r] + bias_r[c];
+                if (vec_out) Os[lrow * OS + col] = z;
                 if (grow < p.N && col < p.H) {
-                    p.Z[(size_t)grow * p.ldz + col] = z;
+                    if (!vec_out) p.Z[(size_t)grow * p.ldz + col] = z;
                     s1 += z;
                     s2 += z * z;
                 }
             }
             st1[c] += (double)s1;
             st2[c] += (double)s2;
+        }
+        if (vec_out) {                                           // (kernel-uniform)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int idx = lane; idx < 32 * O4; idx += 64) {
+                const int row = idx / O4, oc = idx - row * O4;
+                if (r0 + row < p.N)
+                    *reinterpret_cast<float4*>(p.Z + (size_t)(r0 + row) * p.ldz + 4 * oc) =
+                        *reinterpret_cast<const float4*>(Os + row * OS + 4 * oc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -928,9 +950,15 @@ static size_t lin_lds_bytes(int K, int KC, int HT) {
 }
 
 template <int KC, int HT>
-static int launch_lin(const LinArgs& a, int grid, hipStream_t s) {
-    const size_t lds = lin_lds_bytes(a.K, KC, HT);
+static int launch_lin(const LinArgs& a0, int grid, hipStream_t s) {
+    LinArgs a = a0;
+    size_t lds = lin_lds_bytes(a.K, KC, HT);
     if (lds > (size_t)kLdsBudget) return GNM_ERR_UNSUPPORTED;
+    // room for the output staging image (a wide first layer, K = 400 one-hot, has none: 4-byte column stores then)
+    const size_t wbytes = (size_t)(((a.K + KC - 1) / KC) * KC) * HT * 32 * 4 + (size_t)4 * 32 * (KC + 4) * 4;
+    const size_t obytes = (size_t)4 * 32 * (HT * 32 + 4) * 4;
+    a.stage_out = wbytes + obytes <= (size_t)kLdsBudget / 2 ? 1 : 0;      // only while two workgroups still share a CU
+    if (a.stage_out && wbytes + obytes > lds) lds = wbytes + obytes;
     GNM_ALLOW_FULL_LDS((&gnm_lin_kernel<KC, HT>));
     hipLaunchKernelGGL((gnm_lin_kernel<KC, HT>), dim3(grid), dim3(256), lds, s, a);
     GNM_CHECK_LAUNCH();
@@ -967,6 +995,7 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
     a.X = X; a.W = W; a.bias = bias; a.Z = Z; a.pro_scale = pro_scale; a.pro_shift = pro_shift;
     a.stats_partial = stats_partial; a.ldx = ldx; a.ldw = ldw; a.ldz = ldz; a.N = N; a.K = K; a.H = H;
     a.w_kmajor = w_kmajor; a.pro_relu = pro_relu;
+    a.stat_rows = 0; a.stage_out = 0;
 #ifdef GNM_LIN_TUNING
     a.stamps = g_lin_stamps;
 #else
