@@ -1406,7 +1406,7 @@ struct LbArgs {
 // rows are its dX accumulator rows, and no second pass over that array is made.
 template <int KT, int HT, bool STATS, bool NARROW = false, bool SAMEZ = false, bool SPLITD = false>
 __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbArgs p) {   // 2 waves/SIMD: <= 256 registers
-    static_assert(!SPLITD || (SAMEZ && KT == 2 && HT == 2), "SPLITD: the SAMEZ K = H = 64 form only");
+    static_assert(!SPLITD || (HT == 2 && ((SAMEZ && KT == 2) || NARROW)), "SPLITD: H = 64, the SAMEZ K = 64 form or the narrow one");
     static_assert(!NARROW || (KT == 1 && !STATS), "narrow K: one tile, no lower BatchNorm");
     static_assert(!SAMEZ || STATS, "SAMEZ is a STATS variant");
     constexpr int KP = KT * 32, HP = HT * 32;
@@ -1434,7 +1434,8 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
             const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % KT, m = e / (64 * KT);
             float f[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = p.W[(size_t)(8 * m + 32 * kg + j) * p.ldw + 32 * c + n];
+            for (int j = 0; j < 8; ++j)
+                f[j] = (!NARROW || 32 * c + n < p.K) ? p.W[(size_t)(8 * m + 32 * kg + j) * p.ldw + 32 * c + n] : 0.f;
             u32x4 p1, p2, p3;
             lin_split8(f, p1, p2, p3);
             Wp[e] = p1; Wp[EW + e] = p2; Wp[2 * EW + e] = p3;
@@ -2144,7 +2145,8 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
         if (KT == 2 && HT == 2) rc = linbwd_no_split() ? launch_lb_pipe<2, 2>(a, grid, s) : launch_lb_pipe<2, 2, true>(a, grid, s);
     }
     if (narrow && HT == 1) rc = launch_lb<1, 1, false, true>(a, grid, s);
-    if (narrow && HT == 2) rc = launch_lb<1, 2, false, true>(a, grid, s);
+    if (narrow && HT == 2)
+        rc = linbwd_no_split() ? launch_lb<1, 2, false, true>(a, grid, s) : launch_lb<1, 2, false, true, false, true>(a, grid, s);
     if (!pipe && KT == 1 && HT == 1) rc = sZ ? launch_lb<1, 1, true>(a, grid, s) : launch_lb<1, 1, false>(a, grid, s);
     if (!pipe && KT == 2 && HT == 1) rc = sZ ? launch_lb<2, 1, true>(a, grid, s) : launch_lb<2, 1, false>(a, grid, s);
     if (!pipe && KT == 1 && HT == 2) rc = sZ ? launch_lb<1, 2, true>(a, grid, s) : launch_lb<1, 2, false>(a, grid, s);
