@@ -14,14 +14,16 @@ step ends with ONE RCCL all-reduce of the flat gradient buffer.
 
 Prints one JSON line (rank 0).  Extra objects:
   roofline      the sum-aggregation kernel at F = 64 (forward launches, as the step runs them: with the
-                previous layer's BatchNorm+ReLU+readout on the tile load): algorithmic bytes
-                (396,804 B per graph-layer) / mean launch duration from
-                HIP events on the launch stream, against 8 TB/s.
+                previous layer's BatchNorm+ReLU+readout on the tile load): bytes per launch / mean launch duration
+                from HIP events on the launch stream, against 8 TB/s.  Bytes: for the matrix-core kernel the bytes
+                its algorithm MOVES (features in + out + bit adjacency; the PMC-measured traffic when on record), with
+                SURVEY.md 8(d)'s CSR-canonical count (396,804 B per graph-layer) as `frac_csr_equivalent`; for the CSR
+                gather kernels the canonical count itself.
   roofline_mlp  the Linear(64,64) forward launches: bytes in + out against 8 TB/s (the split-precision bf16 kernel
                 is HBM-bound; with GNM_LIN_NO_SPLIT=1 the fp32-MFMA kernel against 157.3 TFLOP/s).
-  cpu_baseline  oracle/gin_oracle.py (numpy/scipy port of the reference's CPU path,
-                pinned to the reference's golden vectors) timed on this host on config
-                C1 (B = 32 of the same graphs), rank 0, N = 1 only.
+  cpu_baseline  oracle/gin_torch_cpu.py (torch-CPU restatement with the reference's own ATen operators, all host
+                cores; pinned to the reference's golden vectors) timed on this host on config C1 (B = 32 of the same
+                graphs), rank 0, N = 1 only; the numpy oracle's time next to it.
 """
 import argparse
 import json
@@ -94,34 +96,48 @@ def measured_traffic(profile_json, csrc_dir, variant):
     return float(ent["hbm_bytes_per_launch"]), ent["source"]
 
 
-def cpu_baseline(graphs, state, budget_s=24.0):
-    """The oracle (kind 'port') on config C1: 32 graphs, fwd + loss + bwd, fp32, both variants SURVEY.md 8(d)
-    asks for: (ii) the full step with the Infomax tail -- `value` -- and (i) encoder + classifier only."""
+def cpu_baseline(graphs, state, budget_s=26.0):
+    """CPU baseline on config C1 (32 graphs, fwd + loss + bwd, fp32) on this host's cores, both variants SURVEY.md 8(d)
+    asks for -- (ii) the full step with the Infomax tail and (i) encoder + classifier only -- from two restatements:
+      * `value`: oracle/gin_torch_cpu.py, the torch-CPU restatement 8(d) specifies (the reference's own ATen operators
+        and cost structure: COO spmm, nn.Bilinear's trilinear autograd), torch.set_num_threads(os.cpu_count());
+      * `numpy_oracle`: oracle/gin_oracle.py, the parity checker (restructured discriminator: faster than the reference)."""
     from oracle import gin_oracle as O
+    from oracle.gin_torch_cpu import TorchCpuGIN
+    ncpu = os.cpu_count() or 1
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
-        threads = os.cpu_count() or 1
+        blas_threads = ncpu
     ob = [O.OGraph(len(g.g), g.edge_mat.numpy(), g.node_features.numpy(), g.label) for g in graphs]
-    model = O.OracleGIN(state, 5, 2, True, "sum", "sum", dtype=np.float32)
     rng = np.random.default_rng(0)
     perm = rng.permutation(len(ob))
 
-    def timed(want_disc, budget):
-        model.train_step_grads(ob, perm, update_running=False, want_disc=want_disc)          # warm-up
+    def timed(fn, budget, warm=1, lo=2, hi=30):
+        for _ in range(warm):
+            fn()
         ts = []
         t_end = time.perf_counter() + budget
-        while len(ts) < 3 or (time.perf_counter() < t_end and len(ts) < 30):
+        while len(ts) < lo or (time.perf_counter() < t_end and len(ts) < hi):
             t0 = time.perf_counter()
-            model.train_step_grads(ob, perm, update_running=False, want_disc=want_disc)
+            fn()
             ts.append(time.perf_counter() - t0)
         return ts
 
-    times = timed(True, budget_s * 0.6)
-    times_i = timed(False, budget_s * 0.4)
-    med = float(np.median(times))
-    med_i = float(np.median(times_i))
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(ncpu)
+    try:
+        tmodel = TorchCpuGIN(state, 5, 2, True, "sum", "sum")
+        t_ii = timed(lambda: tmodel.train_step(ob, perm, 0.05, True), budget_s * 0.45)
+        t_i = timed(lambda: tmodel.train_step(ob, perm, 0.05, False), budget_s * 0.15)
+        torch_threads = torch.get_num_threads()
+    finally:
+        torch.set_num_threads(old_threads)
+    model = O.OracleGIN(state, 5, 2, True, "sum", "sum", dtype=np.float32)
+    n_ii = timed(lambda: model.train_step_grads(ob, perm, update_running=False, want_disc=True), budget_s * 0.25)
+    n_i = timed(lambda: model.train_step_grads(ob, perm, update_running=False, want_disc=False), budget_s * 0.15)
+    med = lambda ts: float(np.median(ts))
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -130,18 +146,25 @@ def cpu_baseline(graphs, state, budget_s=24.0):
                 break
     except Exception:
         pass
-    return {"value": len(ob) / med, "unit": "graphs/s", "cores": int(threads), "kind": "port",
-            "sample": "config C1: %d dense-FC 400-node graphs, fwd+loss+bwd WITH the Infomax tail (variant ii), fp32 "
-                      "numpy/scipy oracle, median of %d steps (%.2f s each)" % (len(ob), len(times), med),
-            "encoder_classifier_only": {"value": len(ob) / med_i, "unit": "graphs/s",
+    return {"value": len(ob) / med(t_ii), "unit": "graphs/s", "cores": int(torch_threads), "kind": "port",
+            "sample": "config C1: %d dense-FC 400-node graphs, fwd+loss+bwd WITH the Infomax tail (variant ii), fp32, "
+                      "torch-CPU restatement (oracle/gin_torch_cpu.py), 1 warm-up + median of %d steps (%.2f s each)"
+                      % (len(ob), len(t_ii), med(t_ii)),
+            "encoder_classifier_only": {"value": len(ob) / med(t_i), "unit": "graphs/s",
                                         "sample": "variant (i): same graphs, CE(c_logit) only, no discriminator; "
-                                                  "median of %d steps (%.2f s each)" % (len(times_i), med_i)},
-            "what_it_is": "oracle/gin_oracle.py: numpy dense algebra on BLAS threads (`cores` = BLAS thread count) + "
-                          "scipy CSR spmm on ONE thread; its discriminator is two [N,LH]x[LH,LH] GEMMs + row dots, "
-                          "algebraically equal to the reference's nn.Bilinear but without autograd's [N,LH,LH]-sized "
-                          "_trilinear intermediates, so it is FASTER than the reference's own CPU path (7.3 graphs/s "
-                          "on 8 cores in the survey container) -- a reported baseline, not a like-for-like one",
-            "host_cpu": cpu, "host_logical_cpus": os.cpu_count()}
+                                                  "median of %d steps (%.2f s each)" % (len(t_i), med(t_i))},
+            "what_it_is": "oracle/gin_torch_cpu.py: the reference's own ATen operators on the host cores "
+                          "(torch.spmm on the uncoalesced COO block adjacency, F.linear, F.batch_norm, F.bilinear with "
+                          "its trilinear autograd) with torch.set_num_threads(os.cpu_count()); pinned to the "
+                          "reference's golden vectors (tests/test_torch_cpu_baseline.py).  Survey container, real "
+                          "reference, 8 cores: 7.3 graphs/s.  A reported baseline, not the optimisation target",
+            "numpy_oracle": {"value": len(ob) / med(n_ii), "unit": "graphs/s", "cores": int(blas_threads),
+                             "encoder_classifier_only": len(ob) / med(n_i),
+                             "sample": "oracle/gin_oracle.py (the parity checker): numpy dense algebra on BLAS threads + "
+                                       "scipy CSR spmm on ONE thread, discriminator restructured as two GEMMs + row dots "
+                                       "(no [N,LH,LH]-sized trilinear intermediates, so faster than the reference's "
+                                       "path); median of %d / %d steps" % (len(n_ii), len(n_i))},
+            "host_cpu": cpu, "host_logical_cpus": ncpu}
 
 
 def main():
@@ -162,7 +185,7 @@ def main():
                     help="c2: 400-node dense-FC graphs, hidden 64 (headline); c4: 1000-node kNN k=20, hidden 128")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from a captured hipGraph.  auto: N > 1 replays every timed step (whichever of "
-                         "replay / eager is faster with the job's collective); N = 1 replays too, except every 4th timed "
+                         "replay / eager is faster with the job's collective); N = 1 replays too, except every 10th timed "
                          "step, which is launched eagerly so that HIP events can bracket the roofline kernels INSIDE the "
                          "timed region.  An all-eager step costs ~2 ms of host time against ~3 ms of GPU time: on a box "
                          "whose host is busy it is host-bound (4.1 ms measured once), replay is not.  off: all eager")
@@ -213,8 +236,20 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # test hook (1-GPU box): GNM_BENCH_FORCE_DIST=1 initialises RCCL ("nccl") at world size 1 and runs the N > 1 step
+    # path on it -- communicator init, the AVG all-reduce of the flat gradients, its capture into the step's hipGraph,
+    # the launch-mode trial.  Two ranks cannot share a GPU under RCCL, so this is as much of the multi-GPU path as one
+    # GPU can execute; the reported line is labelled.
+    forced = world == 1 and os.environ.get("GNM_BENCH_FORCE_DIST") == "1"
+    if forced:
+        os.environ["GNM_DP_FORCE_COLLECTIVE"] = "1"
+    multi = world > 1 or forced
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced and "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -282,8 +317,9 @@ def main():
 
     use_graph = args.graph in ("on", "auto") and not args.sync_bn and args.neighbor_pooling != "max"
     # N = 1, auto: replayed steps with an eager step (HIP events on the roofline kernels) every `timer_every`
-    hybrid = args.graph == "auto" and world == 1 and not args.no_kernel_timer
-    captured = None
+    hybrid = args.graph == "auto" and not multi and not args.no_kernel_timer
+    captured = captured_cc = None
+    capture_notes = {}
     if use_graph:
         from gnm.graphs import CapturedTrainStep
         try:
@@ -291,18 +327,36 @@ def main():
                                          agg0_cache=args.agg0_cache)
         except Exception as e:                      # capture is an optimisation: fall back to eager launches
             print("hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
+            capture_notes["step"] = "%s: %s" % (type(e).__name__, e)
             captured = None
             dp.fp.zero_grad()
+        if captured is not None and multi and not share:
+            # N > 1 on RCCL: a second graph with the gradient all-reduce recorded INSIDE it, behind the backward
+            # (one replay per step, no launch between the last kernel and the collective).  Whether RCCL's
+            # all-reduce captures is a property of the installed build: on any failure the step keeps the
+            # collective outside.  Which variant runs is decided by the timed trial below.
+            try:
+                captured_cc = CapturedTrainStep(model, batches[0][0], loss_fn, zero_grad=dp.zero_grad,
+                                                agg0_cache=args.agg0_cache, post_backward=dp.allreduce_gradients)
+            except Exception as e:
+                print("capturing the all-reduce inside the step's hipGraph failed (%s: %s); it stays outside"
+                      % (type(e).__name__, e), file=sys.stderr)
+                capture_notes["step+allreduce"] = "%s: %s" % (type(e).__name__, e)
+                captured_cc = None
     perms = [np.random.permutation(B) for _ in range(nsteps)]     # graphcnn.py:199, one draw per forward
 
-    use_captured = captured is not None
+    # launch mode of a step: "graph+cc" (replay incl. the collective), "graph" (replay, collective launched behind
+    # it), "eager"
+    mode = "graph" if captured is not None else "eager"
 
     def feats(bt):          # explicit X = aggregate it in the step; None = arena cache (--agg0-cache)
         return None if args.agg0_cache else arena.features(bt)
 
     def step(i, eager=False):
         bt, lab = batches[i]
-        if use_captured and not eager:
+        if mode == "graph+cc" and not eager:
+            return captured_cc.run(bt, lab, perms[i])           # the all-reduce is part of the replayed graph
+        if mode == "graph" and not eager:
             loss = captured.run(bt, lab, perms[i])
         else:
             dp.zero_grad()
@@ -314,12 +368,15 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if captured is not None and args.graph == "auto" and world > 1:
-        # both launch modes are bitwise equivalent; keep whichever is faster together with this job's
-        # collective (decided once, on untimed steps, identically on every rank)
-        def trial(flag, n=3):
-            nonlocal use_captured
-            use_captured = flag
+    trial_ms = None
+    if captured is not None and args.graph == "auto" and multi:
+        # the launch modes are bitwise equivalent; keep whichever is fastest together with this job's collective
+        # (decided once, on untimed steps, identically on every rank: the times are MAX-reduced)
+        from gnm.parallel import choose_launch_mode
+
+        def measure(name, n=3):
+            nonlocal mode
+            mode = name
             step(0)
             torch.cuda.synchronize()
             dist.barrier()
@@ -329,11 +386,16 @@ def main():
             torch.cuda.synchronize()
             tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            return float(tt.item())
-        t_graph, t_eager = trial(True), trial(False)
-        use_captured = t_graph <= t_eager
-    if not use_captured:
+            return float(tt.item()) / n
+        cands = (["graph+cc"] if captured_cc is not None else []) + ["graph", "eager"]
+        mode, trial_s = choose_launch_mode(cands, measure)
+        trial_ms = {k: 1e3 * v for k, v in trial_s.items()}
+    elif captured_cc is not None and args.graph == "on":
+        mode = "graph+cc"
+    if mode == "eager":
         captured = None
+    elif mode == "graph+cc":
+        captured = captured_cc
     kernel_timer = None
     if not args.no_kernel_timer and (captured is None or hybrid):
         kernel_timer = core.KernelTimer(None if args.time_all_kernels else
@@ -343,7 +405,7 @@ def main():
     # (measured: 1.5-2.7 % on the run's average at every 4th): every 10th there (still inside the timed region: 2 steps
     # x 4 / 4 / 9 launches of the three roofline kernels at the default --steps 20)
     timer_every = 1 if args.time_all_kernels or args.steps < 8 else (10 if hybrid and args.steps >= 20 else 4)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -353,12 +415,12 @@ def main():
     core.TIMER = kernel_timer
     t_enqueued = time.perf_counter() - t0        # host time to enqueue all steps (no sync inside)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer, core.TIMER = core.TIMER, None
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -398,8 +460,17 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,
             "launch_mode": ("eager" if captured is None else
                             "hipGraph replay, every %d%s timed step eager with HIP events on the roofline kernels"
-                            % (timer_every, "th" if timer_every > 3 else "") if hybrid else "hipGraph replay"),
+                            % (timer_every, "th" if timer_every > 3 else "") if hybrid else
+                            ("hipGraph replay with the RCCL all-reduce captured inside the graph" if mode == "graph+cc"
+                             else "hipGraph replay")),
         }
+        if multi:
+            out["collective"] = {"backend": dist.get_backend(), "world": world,
+                                 "op": "AVG (1/W inside the collective)" if dp._avg_ok else
+                                       ("SUM + scale launch" if dp._avg_ok is False else "gloo staging (test hook)"),
+                                 "avg_fallback_reason": dp.avg_fallback_reason, "launch_mode_trial_ms": trial_ms,
+                                 "capture_notes": capture_notes or None,
+                                 "forced_single_rank_test_hook": bool(forced)}
         roof, roof_mlp = None, None
         default_cfg = (args.neighbor_pooling, args.graph_pooling, args.keep_pct, args.no_learn_eps) == \
             ("sum", "sum", 30.0, False)
@@ -438,12 +509,27 @@ def main():
                                                             os.path.join(PKG, "csrc"), variant)
                     if per1024 is not None:
                         traffic = per1024 * meta["B"] / 1024.0
+                csr_bytes_launch = bytes_launch
+                if meta.get("mfma"):
+                    # The matrix-core kernel never reads column ids: its algorithm moves features in + result out + the
+                    # graph's bit adjacency (gnm_adj_bits_words: 26,624 B at n = 400) + the node offsets.  `achieved` /
+                    # `frac` are quoted on THOSE bytes (the measured PMC traffic when the committed entry matches this
+                    # kernel source, it agrees with the count to 0.3 %); SURVEY 8(d)'s CSR-canonical count, which this
+                    # kernel does not move, is kept apart as `frac_csr_equivalent`.
+                    bits_b = 4 * int(core.lib.gnm_adj_bits_words(n))
+                    bytes_launch = (4 * n * H * 2 + bits_b + 4 * (n + 1)) * meta["B"]
+                    ach = (traffic if traffic is not None else bytes_launch) / (ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "kernel": kname, "achieved": ach,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "frac_of_measured_copy_peak": ach / HBM_MEASURED_GBS, "traffic": traffic,
                         "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": bytes_launch, "mean_launch_ms": ms, "launches_timed": c,
                         "graph_layers_per_s": meta["B"] / (ms * 1e-3)}
+                if meta.get("mfma"):
+                    roof["achieved_is"] = ("measured HBM traffic (PMC) / launch time" if traffic is not None else
+                                           "bytes the bit-adjacency algorithm moves (features in + out + bits) / launch time")
+                    roof["csr_canonical_bytes_per_launch"] = csr_bytes_launch
+                    roof["frac_csr_equivalent"] = csr_bytes_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 if traffic is not None:
                     # where the kernel moves fewer bytes than the canonical count (16-bit ids, or the bit
                     # adjacency of the matrix-core kernel), also quote the fraction of peak the MOVED bytes amount to
@@ -480,13 +566,27 @@ def main():
                         "kernel": "gnm_agg16_kernel (CSR gather from the LDS tile, plain forward, F=%d), same batch, "
                                   "timed after the run" % H,
                         "median_launch_ms": ms_g, "launches_timed": 20,
-                        "frac": bytes_launch / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                        "frac": csr_bytes_launch / (ms_g * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 bkey = "agg_bwd_F%d" % H
                 bc = [k for k in summ if k == bkey or k.startswith(bkey + "|")]
                 if bc:          # the backward launches (same canonical bytes: g in, dh out, same ids)
                     cb, msb, _ = summ[max(bc, key=lambda k: summ[k][0])]
                     roof["backward"] = {"mean_launch_ms": msb, "launches_timed": cb,
-                                        "frac": bytes_launch / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                        "frac_csr_equivalent": csr_bytes_launch / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    if meta.get("mfma"):
+                        # the fused backward (gnm_aggm_bwd_stats) also reads Z of the layer below for the ReLU mask /
+                        # BatchNorm sums: g in + Z in + dh out + bits (PMC: 357.2 MB per 1024-graph launch)
+                        bwd_b, bsrc = None, None
+                        if default_cfg:
+                            bwd_b, bsrc = measured_traffic(os.path.join(ROOT, "profiles", "agg_traffic.json"),
+                                                           os.path.join(PKG, "csrc"), "mfma_backward_stats")
+                        bwd_bytes = bwd_b * meta["B"] / 1024.0 if bwd_b is not None else \
+                            (4 * n * H * 3 + bits_b + 4 * (n + 1)) * meta["B"]
+                        roof["backward"]["frac"] = bwd_bytes / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS
+                        roof["backward"]["bytes_per_launch"] = bwd_bytes
+                        roof["backward"]["bytes_are"] = "PMC traffic" if bwd_b is not None else "g in + Z in + dh out + bits"
+                    else:
+                        roof["backward"]["frac"] = roof["backward"]["frac_csr_equivalent"]
             key = "lin_fwd_K%d_H%d" % (H, H)
             if key in summ:
                 c, ms, meta = summ[key]
@@ -515,7 +615,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

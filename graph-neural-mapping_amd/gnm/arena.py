@@ -68,7 +68,11 @@ class Batch:
     """What the kernels need to know about one batch of graphs (all on the device)."""
 
     __slots__ = ("B", "N", "n_max", "n_min", "nnz_max", "arena", "node_off", "rp_off", "col_off", "t_rp_off",
-                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base", "bits_off", "t_bits_off", "dense", "maxnb")
+                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base", "bits_off", "t_bits_off", "dense", "maxnb", "iso")
+    # iso: some graph of the batch has a node without neighbours.  Under neighbour "average" + learn_eps that node's
+    # row is 0/0 = NaN (graphcnn.py:157-158) and the reference keeps the NaN to ITS row and its neighbours' -- none -- per
+    # layer; the matrix-core product would spread it to every row of the graph (0 x NaN), so such batches take the
+    # CSR gather in that mode (gnm/core.py _dense)
     # maxnb: gnm.maxnb.MaxNeighbours of the batch when the model pools neighbours with "max" (set by forward())
     # dense: every graph has a bit adjacency and the batch is dense enough for the matrix-core aggregation
     # (DENSE_MIN_FILL); bits_off / t_bits_off: int64 [B] offsets of the forward / transposed bit matrices in arena.bits
@@ -94,6 +98,7 @@ class GraphArena:
         self.bits_off, self.t_bits_off, self.bits_ok = [], [], []
         self.n, self.rp_off, self.col_off, self.t_rp_off, self.t_col_off, self.feat_off, self.nnz = [], [], [], [], [], [], []
         self.sym = []
+        self.iso = []               # per graph: has a node with no neighbours (zero-length CSR row)
         self._dev_tables = None
         self._token = object()
         self._agg0 = {}
@@ -170,7 +175,8 @@ class GraphArena:
                 rps.append(tr[0]); cols.append(tr[1])
                 rp_pos += n + 1; col_pos += E
             fts.append(feats)
-            meta.append((n, E, tr is None, rp_off, col_off, t_rp_off, t_col_off, feat_pos))
+            iso = bool(n > 0 and (np.diff(rowptr) == 0).any())
+            meta.append((n, E, tr is None, rp_off, col_off, t_rp_off, t_col_off, feat_pos, iso))
             feat_pos += n
         if self.feat is None:
             self.feat = _Growable(torch.float32, self.device, width=F0)
@@ -179,8 +185,8 @@ class GraphArena:
         self.col.append(torch.from_numpy(np.concatenate(cols).view(np.int16)))
         self.feat.append(torch.cat(fts, 0) if len(fts) > 1 else fts[0])
         first = len(self.n)
-        for n, E, sym, rp_off, col_off, t_rp_off, t_col_off, feat_off in meta:
-            self.n.append(n); self.nnz.append(E); self.sym.append(sym)
+        for n, E, sym, rp_off, col_off, t_rp_off, t_col_off, feat_off, iso in meta:
+            self.n.append(n); self.nnz.append(E); self.sym.append(sym); self.iso.append(iso)
             self.rp_off.append(rp_off); self.col_off.append(col_off)
             self.t_rp_off.append(t_rp_off); self.t_col_off.append(t_col_off); self.feat_off.append(feat_off)
         self._build_bits(first)
@@ -287,6 +293,7 @@ class GraphArena:
                                     n_host=np.asarray(self.n, dtype=np.int64),
                                     nnz_host=np.asarray(self.nnz, dtype=np.int64),
                                     sym_host=np.asarray(self.sym, dtype=bool),
+                                    iso_host=np.asarray(self.iso, dtype=bool),
                                     rp_host=np.asarray(self.rp_off, dtype=np.int64),
                                     col_host=np.asarray(self.col_off, dtype=np.int64),
                                     trp_host=np.asarray(self.t_rp_off, dtype=np.int64),
@@ -325,6 +332,7 @@ class GraphArena:
         else:
             b.t_rp_off, b.t_col_off = tb["trp"][gd], tb["tcol"][gd]
         b.dense = self.dense_ok(gh)
+        b.iso = bool(tb["iso_host"][gh].any())
         b.bits_off = tb["bits"][gd]
         b.t_bits_off = b.bits_off if b.symmetric else tb["tbits"][gd]
         return b
@@ -452,7 +460,7 @@ class StaticBatch:
 
     def __init__(self, template, extra_int64=0):
         b = Batch()
-        for f in ("B", "N", "n_max", "n_min", "nnz_max", "arena", "symmetric", "dense"):
+        for f in ("B", "N", "n_max", "n_min", "nnz_max", "arena", "symmetric", "dense", "iso"):
             setattr(b, f, getattr(template, f))
         b.node_off_host = np.array(template.node_off_host, copy=True)
         b.node_off = template.node_off.clone()
@@ -474,8 +482,8 @@ class StaticBatch:
 
     def load(self, other, extra=None):
         b = self.batch
-        if (other.B, other.N, other.n_max, other.n_min, other.symmetric, other.dense) != \
-                (b.B, b.N, b.n_max, b.n_min, b.symmetric, b.dense) or other.nnz_max > b.nnz_max:
+        if (other.B, other.N, other.n_max, other.n_min, other.symmetric, other.dense, other.iso) != \
+                (b.B, b.N, b.n_max, b.n_min, b.symmetric, b.dense, b.iso) or other.nnz_max > b.nnz_max:
             raise ValueError("StaticBatch.load: batch shape differs from the captured one")
         if (self.extra is None) != (extra is None):
             raise ValueError("StaticBatch.load: `extra` must be given exactly when the buffer was built with extra_int64")
@@ -500,7 +508,7 @@ class PackedStaticBatch:
     (gnm/graphs.py CapturedEval): assembling a Batch the general way costs ~15 tiny device ops (~150 us of host
     time), which is most of a B = 1 forward."""
 
-    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False):
+    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False, iso=False):
         dev = arena.device
         self.arena, self.B, self.n = arena, int(B), int(n)
         words = 8 * B + (B + 2) // 2                       # 8 int64 vectors + node_off as int32 pairs
@@ -521,6 +529,7 @@ class PackedStaticBatch:
         b.arena, b.B, b.N, b.n_max, b.n_min, b.nnz_max = arena, int(B), int(B * n), int(n), int(n), int(nnz_max)
         b.symmetric = bool(symmetric)
         b.dense = bool(dense)
+        b.iso = bool(iso)
         b.bits_off = dv[6 * B:7 * B]
         b.t_bits_off = b.bits_off if symmetric else dv[7 * B:8 * B]
         b.rp_off, b.col_off = dv[0:B], dv[B:2 * B]
@@ -539,7 +548,7 @@ class PackedStaticBatch:
         b = self.batch
         return (gh.shape[0] == b.B and bool((tb["n_host"][gh] == self.n).all())
                 and bool(tb["sym_host"][gh].all()) == b.symmetric and int(tb["nnz_host"][gh].max()) <= b.nnz_max
-                and self.arena.dense_ok(gh) == b.dense)
+                and self.arena.dense_ok(gh) == b.dense and bool(tb["iso_host"][gh].any()) == b.iso)
 
     def load_gids(self, gh):
         tb = self.arena._tables()

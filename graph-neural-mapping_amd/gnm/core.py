@@ -168,17 +168,22 @@ class GinSpec:
         self.keep_hidden = False
 
 
-def _dense(batch, F_):
+def _dense(batch, F_, spec=None):
     """does this batch take the matrix-core aggregation (csrc/aggm.hip)?  The arena decides per batch (dense graphs
     with a bit adjacency, GraphArena.batch_from_gids); the kernel wants whole 32-column blocks, or one partial block
-    (the input layer's F0 < 32, plain form only: the fused / d-eps forms decline and the gather runs)."""
+    (the input layer's F0 < 32, plain form only: the fused / d-eps forms decline and the gather runs).
+    One mode keeps a dense batch on the CSR gather: neighbour "average" + learn_eps with a node that has no
+    neighbours.  That node's row is 0/0 = NaN in the reference (graphcnn.py:157-158) and stays confined to the rows
+    that gather it; a product multiplies it by the zero bits of every other row of its graph (0 x NaN = NaN)."""
+    if spec is not None and spec.n_avg and spec.learn_eps and getattr(batch, "iso", False):
+        return False
     return bool(getattr(batch, "dense", False)) and (F_ % 32 == 0 or F_ < 32)
 
 
 def agg_partials_capacity(batch, F_):
     """doubles a d-eps partial buffer must hold for this batch, whichever aggregation kernel runs"""
     k = int(lib.gnm_agg_num_partials(F_, batch.n_max, batch.B))
-    if _dense(batch, F_):
+    if _dense(batch, F_):           # (an upper bound: whichever kernel the mode selects)
         k = max(k, int(lib.gnm_aggm_num_partials(F_, batch.B)))
     return k
 
@@ -191,7 +196,7 @@ def _agg(batch, x, y, F_, eps_ptr, spec, backward, hfwd=None, deps_partial=None)
     else:
         rp_off, col_off = batch.rp_off, batch.col_off
     tag = "agg_%s_F%d%s" % ("bwd" if backward else "fwd", F_, "_dot" if y is None else "")
-    if _dense(batch, F_):
+    if _dense(batch, F_, spec):
         bits_off = batch.t_bits_off if backward else batch.bits_off
         with _timed(tag, F=F_, B=batch.B, N=batch.N, mfma=1) as tm:
             rc = lib.gnm_aggm(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), rp_off.data_ptr(), col_off.data_ptr(),
@@ -336,7 +341,7 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
                 z, scale, shift, hout, gslice = pending
                 hout_ptr, hout_ld = (hout.data_ptr(), hout.stride(0)) if hout is not None else (None, 0)
                 rc = -2
-                if _dense(batch, F_l) and not spec.n_max:
+                if _dense(batch, F_l, spec) and not spec.n_max:
                     with _timed("agg_fwd_F%d" % F_l, F=F_l, B=B, N=N, fused_bnrelu=1, mfma=1) as tm:
                         rc = lib.gnm_aggm_fwd_bnrelu(
                             a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
@@ -782,7 +787,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                     spart = torch.empty((B, 2, F_l), dtype=torch.float64, device=dev)
                     a = batch.arena
                     rc = -2
-                    if _dense(batch, F_l):
+                    if _dense(batch, F_l, spec):
                         with _timed("agg_bwd_F%d" % F_l, F=F_l, B=B, N=N, fused_stats=1, mfma=1) as tm:
                             rc = lib.gnm_aggm_bwd_stats(
                                 a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),

@@ -110,7 +110,7 @@ class CapturedEval:
         nnz_cap = max(4096, 1 << (nnz - 1).bit_length()) if nnz > 0 else 4096     # launch parameters sized for this
         self.model = model
         self.static = PackedStaticBatch(arena, gh.shape[0], n, bool(tb["sym_host"][gh].all()), nnz_cap,
-                                        dense=arena.dense_ok(gh))
+                                        dense=arena.dense_ok(gh), iso=bool(tb["iso_host"][gh].any()))
         self.static.load_gids(gh)
         dev = arena.device
         B = gh.shape[0]

@@ -8,6 +8,8 @@ sum.  The model has 142,288 parameters (569 KB) at H=64: the collective is laten
 so all gradients live in one contiguous buffer and a single call moves them.
 BatchNorm statistics are per rank (standard DDP semantics).
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -80,6 +82,11 @@ class DataParallelGIN:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.fp = FlatParams(model)
         self._stage = None          # pinned host staging buffer of the gloo-with-device-tensors path
+        self._avg_ok = None         # does this RCCL take ReduceOp.AVG?  (None: not tried yet)
+        self.avg_fallback_reason = None
+        # test hook: run the collective even at world size 1 (a one-GPU box can then execute the RCCL code path:
+        # communicator init, the AVG all-reduce, its capture into the step's hipGraph)
+        self.force_collective = dist.is_initialized() and os.environ.get("GNM_DP_FORCE_COLLECTIVE") == "1"
         # GIN_InfoMaxReg: let the backward kernels write gradients straight into the flat buffer
         # (overwrite semantics: every step produces every gradient, so no zeroing and no
         # AccumulateGrad adds are needed; see GinSpec.grad_sink)
@@ -122,10 +129,13 @@ class DataParallelGIN:
         self.fp.zero_grad()
 
     def allreduce_gradients(self, async_op=False):
-        """Sum over ranks then scale by 1/W (the mean-loss convention of main.py:34-37
-        applied to the union batch)."""
+        """Mean over ranks of the flat gradient buffer (the mean-loss convention of main.py:34-37 applied to the
+        union batch).  RCCL ("nccl"): ONE collective launch, the 1/W folded into it (ReduceOp.AVG, ncclAvg) -- round 2
+        followed a SUM with a separate g.div_(W) launch.  A build of RCCL that refuses AVG falls back to that pair,
+        once, and remembers.  Nothing here synchronises the host, so the call is hipGraph-capturable on "nccl"
+        (bench.py captures it inside the step's graph when the capture succeeds)."""
         self.fp.attach_grads()      # callers that only ran optimizer.zero_grad(): see zero_grad()
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return None
         g = self.fp.flat_grad
         if g.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -141,11 +151,41 @@ class DataParallelGIN:
             self._stage.div_(self.world)
             g.copy_(self._stage, non_blocking=True)
             return None
+        if self._avg_ok is not False and dist.get_backend(self.group) == "nccl":
+            try:
+                work = dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+                self._avg_ok = True
+                return work if async_op else None
+            except (RuntimeError, ValueError) as e:
+                if self._avg_ok:            # it worked before: this is a real failure, not a missing feature
+                    raise
+                self._avg_ok = False
+                self.avg_fallback_reason = "%s: %s" % (type(e).__name__, e)
         work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
         if async_op:
-            return work
+            return work             # caller scales (FusedAdam.set_grad_scale) after work.wait()
         g.div_(self.world)
         return None
+
+
+def choose_launch_mode(candidates, measure):
+    """Pick how a multi-rank step is launched.  candidates: mode names in order of preference (bench.py: "graph+cc" =
+    hipGraph replay with the all-reduce captured inside, "graph" = replay + collective behind it, "eager");
+    measure(name) -> seconds per step with that mode, already MAX-reduced over the ranks so that every rank takes
+    the same decision.  A candidate whose measurement raises is dropped (e.g. a captured collective that fails at
+    replay); ties go to the earlier candidate.  Returns (mode, {name: seconds})."""
+    times = {}
+    for name in candidates:
+        try:
+            t = float(measure(name))
+        except Exception:
+            continue
+        if t == t and t > 0.0:              # not NaN, a real duration
+            times[name] = t
+    if not times:
+        raise RuntimeError("no launch mode could be measured (candidates: %s)" % ", ".join(candidates))
+    best = min(times, key=lambda k: (times[k], list(candidates).index(k)))
+    return best, times
 
 
 def seed_rank_rng(base_seed, rank):

@@ -43,3 +43,27 @@ def test_bench_other_configurations_print_one_line(extra):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["value"] > 0
     assert out["final_loss"] == out["final_loss"] and abs(out["final_loss"]) < 1e6      # finite
+
+
+@pytest.mark.gpu
+def test_bench_rccl_path_at_world_size_one():
+    """The part of the N > 1 path a one-GPU box CAN run on RCCL itself (two ranks may not share a GPU under RCCL):
+    GNM_BENCH_FORCE_DIST=1 initialises the "nccl" process group at world size 1 and runs the multi-rank step path on
+    it -- communicator init, the AVG all-reduce of the flat gradient buffer (gnm/parallel.py), its capture inside the
+    step's hipGraph, the launch-mode trial.  Lines that had never executed before round 3."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["GNM_BENCH_FORCE_DIST"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "32", "--pool", "64",
+                        "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cc = out["collective"]
+    assert cc["backend"] == "nccl" and cc["forced_single_rank_test_hook"] is True
+    assert cc["op"].startswith(("AVG", "SUM")), cc
+    assert set(cc["launch_mode_trial_ms"]) >= {"graph", "eager"}, cc
+    assert out["value"] > 0 and out["final_loss"] == out["final_loss"]
+    print("collective:", json.dumps(cc))

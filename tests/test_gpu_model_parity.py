@@ -294,6 +294,20 @@ def test_isolated_node_average_nan_matches_reference():
         core.encoder_forward = orig
     assert np.isnan(store["pooled"][0][3]).all()
     assert not np.isnan(store["pooled"][0][0]).any()
+    # every layer, not only the first: the reference keeps the NaN to the isolated node's own row (nobody gathers
+    # it), so hidden[l] / pooled[l] of the OTHER rows stay finite in every layer.  A dense batch in this mode is
+    # routed to the CSR gather for exactly that reason (gnm/core.py _dense: the matrix-core product would spread
+    # 0 x NaN over the whole graph from layer 1 on).
+    O, omodel = oracle_model(cfg, state)
+    og = O.OGraph(cfg["n"], graphs[0].edge_mat.numpy(), graphs[0].node_features.numpy())
+    with np.errstate(all="ignore"):
+        _, _, cache = omodel.forward([og], np.array([0]), training=False)
+    for l in range(cfg["L"]):
+        ref_p, ref_h = cache["layers"][l]["pooled"], cache["hidden"][l]
+        assert np.array_equal(np.isnan(store["pooled"][l]), np.isnan(ref_p)), "pooled %d NaN pattern" % l
+        assert np.array_equal(np.isnan(store["hidden"][l]), np.isnan(ref_h)), "hidden %d NaN pattern" % l
+        assert np.isnan(ref_p[3]).all() and not np.isnan(np.delete(ref_p, 3, 0)).any()
+        assert_close(store["pooled"][l], ref_p, what="pooled %d" % l)
 
 
 def test_non_symmetric_graph_backward_uses_transposed_csr():

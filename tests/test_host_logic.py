@@ -215,3 +215,43 @@ def test_add_many_equals_add_and_symmetry_check():
         assert lib.gnm_csr_from_edge_mat(np.ascontiguousarray(em).ctypes.data, E, n, rp.ctypes.data, col.ctypes.data) == 0
         assert bool(lib.gnm_csr_is_symmetric(rp.ctypes.data, col.ctypes.data, n)) == bool((A == A.T).all()), A
 
+
+
+def test_choose_launch_mode_trial_logic():
+    """bench.py's N > 1 launch-mode trial (gnm.parallel.choose_launch_mode): fastest wins, ties go to the earlier
+    candidate, a candidate that raises (a captured collective failing at replay) or returns garbage is dropped,
+    nothing measurable raises."""
+    from gnm.parallel import choose_launch_mode
+    t = {"graph+cc": 2.0e-3, "graph": 2.2e-3, "eager": 4.0e-3}
+    calls = []
+
+    def measure(name):
+        calls.append(name)
+        return t[name]
+    assert choose_launch_mode(["graph+cc", "graph", "eager"], measure) == ("graph+cc", t)
+    assert calls == ["graph+cc", "graph", "eager"]            # every candidate measured once, in order
+    t2 = dict(t, eager=1.0e-3)
+    assert choose_launch_mode(["graph+cc", "graph", "eager"], lambda n: t2[n])[0] == "eager"
+    assert choose_launch_mode(["graph", "eager"], lambda n: 1.0)[0] == "graph"                     # tie -> preference order
+
+    def flaky(name):
+        if name == "graph+cc":
+            raise RuntimeError("captured collective failed at replay")
+        return float("nan") if name == "graph" else 3.0e-3
+    mode, times = choose_launch_mode(["graph+cc", "graph", "eager"], flaky)
+    assert mode == "eager" and list(times) == ["eager"]
+    with pytest.raises(RuntimeError):
+        choose_launch_mode(["graph"], lambda n: (_ for _ in ()).throw(ValueError("x")))
+
+
+def test_allreduce_gradients_is_a_mean_and_a_noop_for_one_rank():
+    """world size 1: no collective, the flat buffer is untouched (and .grad views are re-attached)."""
+    import torch
+    from gnm.parallel import DataParallelGIN
+    lin = torch.nn.Linear(3, 2)
+    dp = DataParallelGIN(lin, direct_grads=False)
+    dp.zero_grad()
+    lin.weight.grad.fill_(2.0)
+    lin.weight.grad = None
+    assert dp.allreduce_gradients() is None and dp.world == 1
+    assert lin.weight.grad is not None and float(lin.weight.grad.sum()) == 12.0
