@@ -96,6 +96,31 @@ def measured_traffic(profile_json, csrc_dir, variant):
     return float(ent["hbm_bytes_per_launch"]), ent["source"]
 
 
+def usable_cpus():
+    """cores this process may actually run on: the affinity mask, cut by the cgroup CPU quota when there is one
+    (os.cpu_count() is the machine's, and a thread per machine core inside a 16-core share only adds switching)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(graphs, state, budget_s=26.0):
     """CPU baseline on config C1 (32 graphs, fwd + loss + bwd, fp32) on this host's cores, both variants SURVEY.md 8(d)
     asks for -- (ii) the full step with the Infomax tail and (i) encoder + classifier only -- from two restatements:
@@ -104,7 +129,7 @@ def cpu_baseline(graphs, state, budget_s=26.0):
       * `numpy_oracle`: oracle/gin_oracle.py, the parity checker (restructured discriminator: faster than the reference)."""
     from oracle import gin_oracle as O
     from oracle.gin_torch_cpu import TorchCpuGIN
-    ncpu = os.cpu_count() or 1
+    ncpu = usable_cpus()
     try:
         from threadpoolctl import threadpool_info
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
@@ -114,12 +139,18 @@ def cpu_baseline(graphs, state, budget_s=26.0):
     rng = np.random.default_rng(0)
     perm = rng.permutation(len(ob))
 
-    def timed(fn, budget, warm=1, lo=2, hi=30):
-        for _ in range(warm):
-            fn()
+    def timed(fn, budget, hi=30):
+        """one warm-up step, then steps until the budget is spent (at least one).  A warm-up that alone exceeds the
+        budget IS the sample: the baseline must stay bounded on any host (an unbounded 'at least N steps' loop once
+        ran into the driver's limit on a box whose cgroup gave the job a fraction of the cores torch had threads for)"""
+        t0 = time.perf_counter()
+        fn()
+        first = time.perf_counter() - t0
+        if first > budget:
+            return [first]
         ts = []
-        t_end = time.perf_counter() + budget
-        while len(ts) < lo or (time.perf_counter() < t_end and len(ts) < hi):
+        t_end = time.perf_counter() + budget - first
+        while not ts or (time.perf_counter() + float(np.median(ts)) < t_end and len(ts) < hi):
             t0 = time.perf_counter()
             fn()
             ts.append(time.perf_counter() - t0)
@@ -155,7 +186,8 @@ def cpu_baseline(graphs, state, budget_s=26.0):
                                                   "median of %d steps (%.2f s each)" % (len(t_i), med(t_i))},
             "what_it_is": "oracle/gin_torch_cpu.py: the reference's own ATen operators on the host cores "
                           "(torch.spmm on the uncoalesced COO block adjacency, F.linear, F.batch_norm, F.bilinear with "
-                          "its trilinear autograd) with torch.set_num_threads(os.cpu_count()); pinned to the "
+                          "its trilinear autograd) with torch.set_num_threads(cores the job may use: affinity mask and "
+                          "cgroup quota, os.cpu_count() otherwise); pinned to the "
                           "reference's golden vectors (tests/test_torch_cpu_baseline.py).  Survey container, real "
                           "reference, 8 cores: 7.3 graphs/s.  A reported baseline, not the optimisation target",
             "numpy_oracle": {"value": len(ob) / med(n_ii), "unit": "graphs/s", "cores": int(blas_threads),
@@ -164,7 +196,7 @@ def cpu_baseline(graphs, state, budget_s=26.0):
                                        "scipy CSR spmm on ONE thread, discriminator restructured as two GEMMs + row dots "
                                        "(no [N,LH,LH]-sized trilinear intermediates, so faster than the reference's "
                                        "path); median of %d / %d steps" % (len(n_ii), len(n_i))},
-            "host_cpu": cpu, "host_logical_cpus": ncpu}
+            "host_cpu": cpu, "host_logical_cpus": os.cpu_count(), "usable_cpus": ncpu}
 
 
 def main():

@@ -20,6 +20,10 @@ struct HPtrs {
     const float* sc[GNM_MAX_LAYERS];
     const float* sh[GNM_MAX_LAYERS];
 };
+__device__ __forceinline__ float gnm_sigmoid(float v) {      // the form of csrc/tail.hip's BCE gradient
+    const float e = expf(-fabsf(v));
+    return v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+}
 __device__ __forceinline__ float4 gnm_bnrelu4(float4 x, float4 s, float4 h) {
     return make_float4(fmaxf(x.x * s.x + h.x, 0.f), fmaxf(x.y * s.y + h.y, 0.f), fmaxf(x.z * s.z + h.z, 0.f),
                        fmaxf(x.w * s.w + h.w, 0.f));
@@ -29,13 +33,27 @@ __device__ __forceinline__ float4 gnm_bnrelu4(float4 x, float4 s, float4 h) {
 // A row of layer l is covered by H/4 lanes with 16-B loads (G = 64/(H/4) rows per
 // wave-instruction when H/4 divides 64, e.g. 4 rows at H = 64); the lane group reduces its
 // dot product with DPP/shuffle steps inside the group.  Generic widths use one wave per row.
-template <int LPR4>   // lanes per row (H/4), a power of two <= 64; 0 = generic
+//
+// UNIT (round 3): the launch also leaves the backward's per-graph reductions for the reference's own loss,
+// BCEWithLogits against ones (true pairs) / zeros (shuffled pairs) (main.py:32-37), up to the loss's scalar factor k:
+//     d D[v] = k (sigmoid(sc_1[v]) - 1),   d D[N + v] = k sigmoid(sc_2[g(v)])
+//     unit[g, l*H + c] = sum_{v in g} (sigmoid(sc_1[v]) - 1) h_l[v, c] + n_g sigmoid(sc_2[g]) h_l[perm_rows[g], c]   (= dU / k)
+//     unit[g, L*H]     = n_g sigmoid(sc_2[g])                                                                       (= s2sum / k)
+//     unit[g, L*H + 1] = unit[g, L*H] + sum_{v in g} (sigmoid(sc_1[v]) - 1)                                         (= dsum / k)
+//     inv_perm[perm_rows[g]] = g
+// from the rows this kernel holds in registers anyway -- gnm_disc_du_kernel's second pass over the five hidden layers
+// (539 MB at B = 1024) is then not needed: the backward scales `unit` by k (gnm_disc_unit_scale).  It cannot be folded
+// into the aggregation-backward epilogues instead: those CONSUME the readout gradient
+// dpool = f(dU W), so all of dU must exist before the first of them runs.
+template <int LPR4, bool UNIT = false>   // lanes per row (H/4), a power of two <= 64; 0 = generic
 __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, int ldh, int L, int H,
                                                              const float* __restrict__ U, int ldu,
                                                              const int32_t* __restrict__ perm_rows,
                                                              const float* __restrict__ bias,
                                                              const int32_t* __restrict__ node_off, int N,
-                                                             float* __restrict__ d_logit) {
+                                                             float* __restrict__ d_logit,
+                                                             float* __restrict__ unit, int ldunit,
+                                                             int32_t* __restrict__ inv_perm) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Us = reinterpret_cast<float*>(smem);        // [L*H]
     float* Ss = Us + L * H;                            // [L*H] BatchNorm scale / shift of the layers given as Z
@@ -71,7 +89,13 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
     }
     __syncthreads();
     const float sc2 = sc2s[0];
-    if (n <= 0) return;
+    if (n <= 0) {
+        if constexpr (UNIT) {          // an empty graph: empty sums
+            for (int e = tid; e < L * H + 2; e += nthreads) unit[(size_t)g * ldunit + e] = 0.f;
+            if (tid == 0) inv_perm[perm_rows[g]] = g;
+        }
+        return;
+    }
     if constexpr (LPR4 > 0) {
         constexpr int G = 64 / LPR4;                   // rows per wave-instruction
         const int sub = lane & (LPR4 - 1), slot = lane / LPR4;
@@ -106,7 +130,9 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
                 if (tmask >> l & 1)                                                                              \
                     x = gnm_bnrelu4(x, *reinterpret_cast<const float4*>(Ss + min(l, L - 1) * H + 4 * sub),       \
                                     *reinterpret_cast<const float4*>(Sh + min(l, L - 1) * H + 4 * sub));         \
-                a += x.x * uu[l].x + x.y * uu[l].y + x.z * uu[l].z + x.w * uu[l].w;                              \
+                xx[l] = x;                                                                                       \
+                const float dl = x.x * uu[l].x + x.y * uu[l].y + x.z * uu[l].z + x.w * uu[l].w;                  \
+                a += l < L ? dl : 0.f;      /* a padding slot re-reads layer L - 1: keep a non-finite z out */   \
             }                                                                                                    \
             for (int l = ML; l < L; ++l) {                                                                       \
                 float4 x = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)v * ldh + 4 * sub);                \
@@ -117,6 +143,14 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
                 a += x.x * u.x + x.y * u.y + x.z * u.z + x.w * u.w;                                              \
             }                                                                                                    \
             _Pragma("unroll") for (int off = LPR4 >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);         \
+            if constexpr (UNIT) {         /* every lane of the row's group holds the whole dot product */        \
+                const float wv = (r_) < n ? gnm_sigmoid(a + bv) - 1.f : 0.f;                                     \
+                s1u += sub == 0 ? wv : 0.f;                                                                      \
+                _Pragma("unroll") for (int l = 0; l < ML; ++l) {                                                 \
+                    du[l].x += wv * xx[l].x; du[l].y += wv * xx[l].y;                                            \
+                    du[l].z += wv * xx[l].z; du[l].w += wv * xx[l].w;                                            \
+                }                                                                                                \
+            }                                                                                                    \
             const bool wr = sub == 0 && (r_) < n;                                                                \
             const unsigned o1 = wr ? (unsigned)v * 4u : 0xFFFFFFF0u;                                             \
             const unsigned o2 = wr ? (unsigned)(N + v) * 4u : 0xFFFFFFF0u;                                       \
@@ -124,6 +158,10 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc2), rd, o2, 0, 0);                           \
         }
         float4 xa[ML], xb[ML];
+        float4 du[ML];
+        float s1u = 0.f;
+#pragma unroll
+        for (int l = 0; l < ML; ++l) du[l] = make_float4(0.f, 0.f, 0.f, 0.f);
         int r = wave * G + slot;
         GNM_DS_LOAD(xa, r)
         for (; r - slot < n; r += 2 * stride) {         // wave-uniform trip count (r - slot is the wave's first row)
@@ -134,6 +172,46 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
         }
 #undef GNM_DS_LOAD
 #undef GNM_DS_FINISH
+        if constexpr (UNIT) {
+            // fixed-order reduction: the row slots of a wave (lanes with equal `sub`), then the waves through LDS
+            float4* red = reinterpret_cast<float4*>(sc2s + 4);            // [nwaves][ML][LPR4]
+            float* s1red = reinterpret_cast<float*>(red + nwaves * ML * LPR4);
+#pragma unroll
+            for (int l = 0; l < ML; ++l) {
+#pragma unroll
+                for (int off = LPR4; off < 64; off <<= 1) {
+                    du[l].x += __shfl_xor(du[l].x, off, 64); du[l].y += __shfl_xor(du[l].y, off, 64);
+                    du[l].z += __shfl_xor(du[l].z, off, 64); du[l].w += __shfl_xor(du[l].w, off, 64);
+                }
+                if (lane < LPR4) red[(wave * ML + l) * LPR4 + lane] = du[l];
+            }
+            s1u = wave_sum(s1u);
+            if (lane == 0) s1red[wave] = s1u;
+            __syncthreads();
+            const float s2u = (float)n * gnm_sigmoid(sc2);
+            const int pr = perm_rows[g];
+            for (int e = tid; e < L * LPR4; e += nthreads) {
+                const int l = e / LPR4, c4 = e - l * LPR4;
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int w = 0; w < nwaves; ++w) {
+                    const float4 q = red[(w * ML + l) * LPR4 + c4];
+                    t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+                }
+                float4 x = *reinterpret_cast<const float4*>(hp.p[l] + (size_t)pr * ldh + 4 * c4);
+                if (tmask >> l & 1)
+                    x = gnm_bnrelu4(x, *reinterpret_cast<const float4*>(Ss + l * H + 4 * c4),
+                                    *reinterpret_cast<const float4*>(Sh + l * H + 4 * c4));
+                t.x += s2u * x.x; t.y += s2u * x.y; t.z += s2u * x.z; t.w += s2u * x.w;
+                *reinterpret_cast<float4*>(unit + (size_t)g * ldunit + (size_t)l * H + 4 * c4) = t;
+            }
+            if (tid == 0) {
+                float s1 = 0.f;
+                for (int w = 0; w < nwaves; ++w) s1 += s1red[w];
+                unit[(size_t)g * ldunit + (size_t)L * H] = s2u;
+                unit[(size_t)g * ldunit + (size_t)L * H + 1] = s2u + s1;
+                inv_perm[pr] = g;
+            }
+        }
     } else {
         for (int r = wave; r < n; r += nwaves) {
             const int v = row0 + r;
@@ -163,26 +241,85 @@ static void fill_hptrs(HPtrs& hp, const float* const* hptrs, const float* const*
     }
 }
 
-extern "C" int gnm_disc_score_fwd(const float* const* hptrs, const float* const* scale_ptrs,
-                                  const float* const* shift_ptrs, int ldh, int L, int H, const float* U, int ldu,
-                                  const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
-                                  float* d_logit, void* stream) {
+static int disc_score_launch(const float* const* hptrs, const float* const* scale_ptrs, const float* const* shift_ptrs,
+                             int ldh, int L, int H, const float* U, int ldu, const int32_t* perm_rows,
+                             const float* bias, const int32_t* node_off, int N, int B, float* d_logit, float* unit,
+                             int ldunit, int32_t* inv_perm, void* stream) {
     if (B <= 0) return GNM_OK;
     if (L <= 0 || L > GNM_MAX_LAYERS || H <= 0) return GNM_ERR_BAD_ARG;
     HPtrs hp;
     fill_hptrs(hp, hptrs, scale_ptrs, shift_ptrs, L);
-    const size_t lds = (size_t)(3 * L * H + 4) * 4;
+    const int threads = B >= 1024 ? 256 : 1024;
+    size_t lds = (size_t)(3 * L * H + 4) * 4;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool vec = ((ldh & 3) == 0) && ((H & 3) == 0);
     const int lpr4 = vec ? H / 4 : 0;
-#define GNM_DISC_CASE(V) \
-    hipLaunchKernelGGL(gnm_disc_score_kernel<V>, dim3(B), dim3(B >= 1024 ? 256 : 1024), lds, st, hp, ldh, L, H, U, ldu, perm_rows, bias, \
-                       node_off, N, d_logit)
-    if (lpr4 == 8) GNM_DISC_CASE(8);
-    else if (lpr4 == 16) GNM_DISC_CASE(16);
-    else if (lpr4 == 32) GNM_DISC_CASE(32);
-    else GNM_DISC_CASE(0);
+    if (unit) {
+        // the by-products ride on the register-resident row groups of the vector forms (at most 5 layers in flight)
+        if (!(lpr4 == 8 || lpr4 == 16 || lpr4 == 32) || L > 5 || (ldunit & 3) || ldunit < L * H + 2 || !inv_perm ||
+            (reinterpret_cast<uintptr_t>(unit) & 15))
+            return GNM_ERR_UNSUPPORTED;
+        lds += 16 + (size_t)(threads / 64) * 5 * lpr4 * 16 + (size_t)(threads / 64) * 4;
+    }
+#define GNM_DISC_CASE(V, UN)                                                                                          \
+    hipLaunchKernelGGL((gnm_disc_score_kernel<V, UN>), dim3(B), dim3(threads), lds, st, hp, ldh, L, H, U, ldu,          \
+                       perm_rows, bias, node_off, N, d_logit, unit, ldunit, inv_perm)
+    if (unit) {
+        if (lpr4 == 8) GNM_DISC_CASE(8, true);
+        else if (lpr4 == 16) GNM_DISC_CASE(16, true);
+        else GNM_DISC_CASE(32, true);
+    } else if (lpr4 == 8) GNM_DISC_CASE(8, false);
+    else if (lpr4 == 16) GNM_DISC_CASE(16, false);
+    else if (lpr4 == 32) GNM_DISC_CASE(32, false);
+    else GNM_DISC_CASE(0, false);
 #undef GNM_DISC_CASE
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+extern "C" int gnm_disc_score_fwd(const float* const* hptrs, const float* const* scale_ptrs,
+                                  const float* const* shift_ptrs, int ldh, int L, int H, const float* U, int ldu,
+                                  const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
+                                  float* d_logit, void* stream) {
+    return disc_score_launch(hptrs, scale_ptrs, shift_ptrs, ldh, L, H, U, ldu, perm_rows, bias, node_off, N, B,
+                             d_logit, nullptr, 0, nullptr, stream);
+}
+
+// gnm_disc_score_fwd that also leaves the backward's reductions for the reference's BCE-with-logits loss up to its
+// scalar factor (see the kernel): unit [B, ldunit >= L*H + 2], inv_perm [B].  GNM_ERR_UNSUPPORTED outside the vector
+// forms (H / 4 in {8, 16, 32}, L <= 5): call gnm_disc_score_fwd and, in the backward, gnm_disc_score_bwd.
+extern "C" int gnm_disc_score_fwd_unit(const float* const* hptrs, const float* const* scale_ptrs,
+                                       const float* const* shift_ptrs, int ldh, int L, int H, const float* U, int ldu,
+                                       const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N,
+                                       int B, float* d_logit, float* unit, int ldunit, int32_t* inv_perm,
+                                       void* stream) {
+    if (!unit) return GNM_ERR_BAD_ARG;
+    return disc_score_launch(hptrs, scale_ptrs, shift_ptrs, ldh, L, H, U, ldu, perm_rows, bias, node_off, N, B,
+                             d_logit, unit, ldunit, inv_perm, stream);
+}
+
+// dU = k unit[:, :LH], s2sum = k unit[:, LH], dsum = k unit[:, LH + 1]; k a device scalar (the loss's factor times the
+// upstream gradient).  What gnm_disc_score_bwd would have produced from dD = k (sigmoid(d_logit) - target).
+__global__ void __launch_bounds__(256) gnm_disc_unit_scale_kernel(const float* __restrict__ unit, int ldunit, int LH,
+                                                                  const float* __restrict__ k, float* __restrict__ dU,
+                                                                  int ldu, float* __restrict__ s2sum,
+                                                                  float* __restrict__ dsum) {
+    const int g = blockIdx.x;
+    const float kv = *k;
+    const float* row = unit + (size_t)g * ldunit;
+    for (int e = threadIdx.x; e < LH; e += blockDim.x) dU[(size_t)g * ldu + e] = kv * row[e];
+    if (threadIdx.x == 0) {
+        s2sum[g] = kv * row[LH];
+        if (dsum) dsum[g] = kv * row[LH + 1];
+    }
+}
+
+extern "C" int gnm_disc_unit_scale(const float* unit, int ldunit, int LH, const float* k, int B, float* dU, int ldu,
+                                   float* s2sum, float* dsum, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (!unit || !k || !dU || !s2sum || LH <= 0 || ldunit < LH + 2) return GNM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gnm_disc_unit_scale_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), unit,
+                       ldunit, LH, k, dU, ldu, s2sum, dsum);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }

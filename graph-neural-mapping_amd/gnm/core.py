@@ -421,6 +421,28 @@ def encoder_forward(spec, batch, X, P, training, update_running, P0=None):
     return hidden, g_f, saved
 
 
+class DiscUnit:
+    """Hand-over between the discriminator scores' forward, the loss and the backward (round 3).
+
+    With the reference's loss on d_logit -- BCEWithLogits against ones / zeros, main.py:32-37 -- the backward's
+    per-graph reductions (dU, s2sum, dsum of gnm_disc_score_bwd) are k x quantities that depend on the FORWARD values
+    only, k being the loss's scalar factor times the upstream gradient.  gnm_disc_score_fwd_unit leaves them in `unit`
+    from the hidden rows it holds in registers anyway; a loss that knows it has that form (gnm.train.infomax_loss with
+    its default targets) records k and the gradient tensor it handed to autograd; GinInfoMaxFn.backward then scales
+    `unit` instead of reading the five hidden layers a second time (gnm_disc_du_kernel: 539 MB, ~90 us at B = 1024).
+    Any other loss (main.py's torch losses, explicit d_labels, a d_logit that also feeds something else so that
+    autograd SUMS gradients into a new tensor) leaves k unset or the pointer different, and the backward runs
+    gnm_disc_score_bwd exactly as before."""
+    __slots__ = ("unit", "inv_perm", "k", "dD_ptr")
+
+    def __init__(self):
+        self.unit = self.inv_perm = self.k = self.dD_ptr = None
+
+
+# GNM_NO_DISC_UNIT=1: never produce the by-products (A/B timing against gnm_disc_score_bwd's pass)
+DISC_UNIT = os.environ.get("GNM_NO_DISC_UNIT") is None
+
+
 class ZAct:
     """A layer output that is not in memory: h = relu(z * scale + shift) (graphcnn.py:163-166) with z the pre-BatchNorm
     output of the layer's last Linear and (scale, shift) its folded BatchNorm.  Its BatchNorm + ReLU ran on the tile
@@ -527,6 +549,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                 c = torch.sigmoid(g_f)
         d_logit = None
         U = perm_rows = None
+        disc_unit = None
         if want_disc:
             if not batch.equal_n:
                 raise RuntimeError("Discriminator expands each graph summary N//B times (discriminator.py:24): "
@@ -542,15 +565,32 @@ class GinInfoMaxFn(torch.autograd.Function):
                 perm_rows = torch.as_tensor(perm, dtype=torch.int32).pin_memory().to(X.device, non_blocking=True)
             d_logit = torch.empty((2 * N, 1), dtype=torch.float32, device=X.device)
             hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
-            check(lib.gnm_disc_score_fwd(hp_, sp_, tp_, ldh_, L, H, U.data_ptr(), U.stride(0),
-                                         perm_rows.data_ptr(), P["disc.f_k.bias"].data_ptr(),
-                                         batch.node_off.data_ptr(), N, B, d_logit.data_ptr(), _stream()),
-                  "gnm_disc_score_fwd")
+            rc = -2
+            if isinstance(want_disc, DiscUnit) and training:
+                # also leave the backward's per-graph reductions (up to the loss's scalar factor): see DiscUnit
+                ldunit = (L * H + 2 + 3) & ~3
+                unit = torch.empty((B, ldunit), dtype=torch.float32, device=X.device)
+                inv_perm = torch.empty(B, dtype=torch.int32, device=X.device)
+                rc = lib.gnm_disc_score_fwd_unit(hp_, sp_, tp_, ldh_, L, H, U.data_ptr(), U.stride(0),
+                                                 perm_rows.data_ptr(), P["disc.f_k.bias"].data_ptr(),
+                                                 batch.node_off.data_ptr(), N, B, d_logit.data_ptr(), unit.data_ptr(),
+                                                 ldunit, inv_perm.data_ptr(), _stream())
+                if rc == 0:
+                    want_disc.unit, want_disc.inv_perm = unit, inv_perm
+                    disc_unit = want_disc
+                elif rc != -2:
+                    check(rc, "gnm_disc_score_fwd_unit")
+            if rc == -2:
+                check(lib.gnm_disc_score_fwd(hp_, sp_, tp_, ldh_, L, H, U.data_ptr(), U.stride(0),
+                                             perm_rows.data_ptr(), P["disc.f_k.bias"].data_ptr(),
+                                             batch.node_off.data_ptr(), N, B, d_logit.data_ptr(), _stream()),
+                      "gnm_disc_score_fwd")
         ctx.spec, ctx.batch, ctx.names, ctx.P = spec, batch, names, P
         ctx.hidden, ctx.saved, ctx.g_f, ctx.masks, ctx.Wp = hidden, saved, g_f, masks, Wp
         ctx.fused_head, ctx.wps = fused_head, wps
         ctx.c, ctx.U, ctx.perm_rows, ctx.perm = c, U, perm_rows, perm
         ctx.training, ctx.X = training, X
+        ctx.disc_unit = disc_unit
         ctx.mark_non_differentiable(g_f)
         if d_logit is None:
             d_logit = torch.zeros((0, 1), dtype=torch.float32, device=X.device)
@@ -595,12 +635,24 @@ class GinInfoMaxFn(torch.autograd.Function):
             dU = torch.empty_like(U)
             s2sum = torch.empty(B, **f32)
             dsum = torch.empty(B, **f32)
-            inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
-            hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
-            check(lib.gnm_disc_score_bwd(hp_, sp_, tp_, ldh_, L, H, dD.data_ptr(),
-                                         ctx.perm_rows.data_ptr(), batch.node_off.data_ptr(), N, B, dU.data_ptr(),
-                                         dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(), inv_perm.data_ptr(), st),
-                  "gnm_disc_score_bwd")
+            hold = ctx.disc_unit
+            if hold is not None and hold.k is not None and hold.dD_ptr == dD.data_ptr():
+                # dD = k (sigmoid(d_logit) - target) came straight from the loss that recorded k: the reductions are k
+                # times what the forward left (DiscUnit) -- no second pass over the hidden layers
+                inv_perm = hold.inv_perm
+                check(lib.gnm_disc_unit_scale(hold.unit.data_ptr(), hold.unit.stride(0), L * H, hold.k.data_ptr(), B,
+                                              dU.data_ptr(), dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(), st),
+                      "gnm_disc_unit_scale")
+            else:
+                inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
+                hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
+                with _timed("disc_du", N=N, L=L, H=H):
+                    check(lib.gnm_disc_score_bwd(hp_, sp_, tp_, ldh_, L, H, dD.data_ptr(),
+                                                 ctx.perm_rows.data_ptr(), batch.node_off.data_ptr(), N, B,
+                                                 dU.data_ptr(), dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(),
+                                                 inv_perm.data_ptr(), st), "gnm_disc_score_bwd")
+            if hold is not None:
+                hold.k = hold.dD_ptr = None
             Wd = P["disc.f_k.weight"][0]
             if sink is not None:
                 torch.mm(dU.t(), c, out=sink["disc.f_k.weight"][0])

@@ -26,7 +26,7 @@ from .parallel import DataParallelGIN
 
 class _InfomaxLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, c_logit, d_logit, labels, d_target, beta, n_pos):
+    def forward(ctx, c_logit, d_logit, labels, d_target, beta, n_pos, hold=None):
         if not c_logit.is_cuda:
             raise RuntimeError("infomax_loss runs on the GPU only (libgnm_hip.so)")
         c = c_logit.contiguous()
@@ -48,6 +48,8 @@ class _InfomaxLossFn(torch.autograd.Function):
             check(lib.gnm_loss_ce_bce(c.data_ptr(), c.stride(0), lab.data_ptr(), B, C_, d.data_ptr(),
                                       tgt.data_ptr() if tgt is not None else None, M, int(n_pos), float(beta),
                                       loss3.data_ptr(), None, 0, None, ws.data_ptr(), _stream()), "gnm_loss_ce_bce")
+        # hold: the model's DiscUnit hand-over (gnm/core.py), only with the reference's default targets
+        ctx.hold = hold if (tgt is None and 2 * int(n_pos) == M and M > 0) else None
         ctx.args = (c, d, lab, tgt, int(n_pos), float(beta), d_logit.shape)
         parts = loss3.detach()
         ctx.mark_non_differentiable(parts)
@@ -65,7 +67,13 @@ class _InfomaxLossFn(torch.autograd.Function):
                                            tgt.data_ptr() if tgt is not None else None, M, n_pos, beta, g.data_ptr(),
                                            dC.data_ptr(), dC.stride(0), dD.data_ptr(), _stream()),
                   "gnm_loss_ce_bce_grad")
-        return dC, dD.view(dshape), None, None, None, None
+        dD = dD.view(dshape)
+        if ctx.hold is not None:
+            # dD = k (sigmoid(d_logit) - target) with the kernel's fp32 factor k = upstream * (beta / M): the model's
+            # backward scales the reductions its forward left instead of re-reading the hidden layers
+            ctx.hold.k = g.reshape(1) * float(np.float32(beta) / np.float32(M))
+            ctx.hold.dD_ptr = dD.data_ptr()
+        return dC, dD, None, None, None, None, None
 
 
 def infomax_loss(c_logit, d_logit, labels, beta=0.05, d_labels=None):
@@ -74,7 +82,8 @@ def infomax_loss(c_logit, d_logit, labels, beta=0.05, d_labels=None):
     shuffled half (main.py:32 with the node count).  Returns (loss, parts) with parts = [loss, c_loss, d_loss]
     (detached, on the device: reading them is the caller's sync, as main.py:43 does)."""
     n_pos = d_logit.numel() // 2
-    return _InfomaxLossFn.apply(c_logit, d_logit, labels, d_labels, beta, n_pos)
+    hold = getattr(d_logit, "_gnm_disc_unit", None) if d_labels is None else None
+    return _InfomaxLossFn.apply(c_logit, d_logit, labels, d_labels, beta, n_pos, hold)
 
 
 class FusedAdam:

@@ -32,7 +32,7 @@ for _p in (_PKG, _HERE):
 from mlp import MLP  # noqa: E402
 from discriminator import Discriminator  # noqa: E402
 from gnm.arena import GraphArena  # noqa: E402
-from gnm.core import GinInfoMaxFn, GinSpec  # noqa: E402
+from gnm.core import DISC_UNIT, DiscUnit, GinInfoMaxFn, GinSpec  # noqa: E402
 
 __all__ = ["GIN_InfoMaxReg", "GraphCNN", "MLP", "Discriminator"]
 
@@ -143,8 +143,16 @@ class GIN_InfoMaxReg(nn.Module):
 
     def _run(self, batch, X, perm, want_disc, P0=None):
         names, tensors, buffers = self._param_lists()
-        return GinInfoMaxFn.apply(self._spec, batch, perm, names, buffers, self.training, float(self.final_dropout),
-                                  want_disc, P0, X, *tensors)
+        hold = None
+        if want_disc and self.training and DISC_UNIT and torch.is_grad_enabled():
+            # let the score kernel leave the backward's reductions for the reference's BCE loss (gnm/core.py DiscUnit);
+            # only a loss that recognises the hand-over on d_logit (gnm.train.infomax_loss) makes use of it
+            hold = want_disc = DiscUnit()
+        out = GinInfoMaxFn.apply(self._spec, batch, perm, names, buffers, self.training, float(self.final_dropout),
+                                 want_disc, P0, X, *tensors)
+        if hold is not None and hold.unit is not None:
+            out[1]._gnm_disc_unit = hold
+        return out
 
     def forward_batch(self, batch, X=None, perm=None, latent=False):
         """forward() for an already assembled gnm.arena.Batch (what bench.py and the

@@ -238,6 +238,22 @@ int gnm_disc_score_fwd(const float* const* hptrs_host, const float* const* scale
                        const float* const* shift_ptrs_host, int ldh, int L, int H, const float* U, int ldu,
                        const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
                        float* d_logit, void* stream);
+/* gnm_disc_score_fwd that ALSO leaves the reductions its backward needs, for the loss the reference applies to
+ * d_logit -- BCEWithLogitsLoss against ones for the first N entries and zeros for the rest (main.py:32-37) -- up to that
+ * loss's scalar factor k (= upstream gradient * beta / 2N):
+ *   unit[g, l*H + c] = dU[g, l*H + c] / k,  unit[g, L*H] = s2sum[g] / k,  unit[g, L*H + 1] = dsum[g] / k   (ldunit >=
+ *   L*H + 2, a multiple of 4, 16-byte aligned base),  inv_perm[perm_rows[g]] = g.
+ * They come from the hidden rows the score kernel holds in registers anyway, so gnm_disc_score_bwd's second pass over
+ * the L hidden layers (539 MB at B = 1024) is not needed: the backward calls gnm_disc_unit_scale with k.  A caller whose
+ * loss on d_logit is anything else ignores `unit` and calls gnm_disc_score_bwd as before.
+ * GNM_ERR_UNSUPPORTED outside the vector forms (H / 4 in {8, 16, 32}, L <= 5, ldh % 4 == 0). */
+int gnm_disc_score_fwd_unit(const float* const* hptrs_host, const float* const* scale_ptrs_host,
+                            const float* const* shift_ptrs_host, int ldh, int L, int H, const float* U, int ldu,
+                            const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
+                            float* d_logit, float* unit, int ldunit, int32_t* inv_perm, void* stream);
+/* dU = k * unit[:, :LH], s2sum = k * unit[:, LH], dsum = k * unit[:, LH + 1] (dsum may be NULL); k: DEVICE scalar. */
+int gnm_disc_unit_scale(const float* unit, int ldunit, int LH, const float* k, int B, float* dU, int ldu,
+                        float* s2sum, float* dsum, void* stream);
 /* optional by-products: dsum[g] = sum over graph g of dD (both halves; their total is d bias), and
  * inv_perm[perm_rows[g]] = g. */
 int gnm_disc_score_bwd(const float* const* hptrs_host, const float* const* scale_ptrs_host,

@@ -83,9 +83,15 @@ def test_aggm_forward_backward(sizes, density, F, symmetric, average, learn_eps)
     ar = GraphArena(DEV)
     batch = ar.batch(graphs)
     assert batch.dense and core._dense(batch, F)
+    # this test drives the matrix-core kernel itself, isolated nodes included (their 0/0 under average + learn_eps
+    # stays in the row: the inputs are finite).  The model-level routing of such batches to the CSR gather
+    # (core._dense with a spec) is switched off here and tested in test_dense_routing_of_isolated_nodes below.
+    has_iso = batch.iso
+    batch.iso = False
     A = dense_adj(graphs)
     N = batch.N
     deg = np.asarray(A.sum(1)).reshape(-1, 1)
+    assert has_iso == bool((deg == 0).any())
     x = rng.standard_normal((N, F)) * np.exp(rng.standard_normal((N, 1)) * 2)     # rows of very different scale
     eps = 0.37
     spec = core.GinSpec(1, 1, bool(learn_eps), "sum", "average" if average else "sum")
@@ -323,3 +329,24 @@ def test_aggm_refuses_what_it_does_not_cover():
     # a sparse batch is left to the gather by the arena
     sparse = ar.batch(random_graphs(rng, [300, 300], 0.02, True))
     assert not sparse.dense
+
+
+def test_dense_routing_of_isolated_nodes():
+    """A dense batch with a zero-degree node takes the CSR gather under neighbour average + learn_eps (the one mode in
+    which that node's row is 0/0 = NaN, graphcnn.py:157-158, and a product would spread it over its graph from the next
+    layer on); every other mode, and every batch without such a node, keeps the matrix-core kernel."""
+    from gnm import core
+    from gnm.arena import GraphArena
+    rng = np.random.default_rng(3)
+    ar = GraphArena(DEV)
+    full = ar.batch(random_graphs(rng, [40, 40], 1.0, True))
+    g_iso = random_graphs(rng, [40, 40], 0.5, True)
+    em = g_iso[1].edge_mat.numpy()
+    g_iso[1].edge_mat = torch.from_numpy(np.ascontiguousarray(em[:, (em[0] != 7) & (em[1] != 7)]))
+    iso = ar.batch(g_iso)
+    assert full.dense and not full.iso and iso.dense and iso.iso
+    for npool in ("sum", "average"):
+        for learn_eps in (True, False):
+            spec = core.GinSpec(2, 2, learn_eps, "sum", npool)
+            assert core._dense(full, 64, spec)
+            assert core._dense(iso, 64, spec) == (not (npool == "average" and learn_eps))

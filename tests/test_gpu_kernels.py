@@ -589,6 +589,93 @@ def test_discriminator_scores_vs_literal_bilinear(B, n, L, H, as_z):
     assert_close(dU.cpu().numpy(), dU_ref, rtol=TOL, what="dU", floor=1e-3 * np.abs(dU_ref).max())
 
 
+@pytest.mark.parametrize("B,n,L,H", [(3, 24, 5, 64), (4, 20, 3, 32), (2, 1, 2, 64), (5, 400, 5, 64), (1100, 8, 5, 64),
+                                     (3, 40, 4, 128)])
+@pytest.mark.parametrize("as_z", [False, True])
+def test_discriminator_unit_reductions_equal_the_backward_pass(B, n, L, H, as_z):
+    """gnm_disc_score_fwd_unit: same d_logit as gnm_disc_score_fwd (bitwise: same kernel body), and its by-products,
+    scaled by gnm_disc_unit_scale, are what gnm_disc_score_bwd computes from dD = k (sigmoid(d_logit) - target) -- the
+    gradient of beta * BCEWithLogits against ones / zeros (main.py:32-37) -- and what fp64 says.  (1100 graphs: the
+    256-thread workgroup form; 3 graphs: 1024 threads.)"""
+    from gnm._cabi import check, lib
+    rng = np.random.default_rng(B * 7 + n)
+    N, LH = B * n, L * H
+    zs = [rng.standard_normal((N, H)).astype(np.float32) for _ in range(L)]
+    scs = [rng.uniform(0.5, 1.5, H).astype(np.float32) for _ in range(L)]
+    shs = [(rng.standard_normal(H) * 0.3).astype(np.float32) for _ in range(L)]
+    given_as_z = [as_z and l < L - 1 for l in range(L)]
+    hs = [np.maximum(zs[l] * scs[l] + shs[l], np.float32(0)) if given_as_z[l] else zs[l] for l in range(L)]
+    n_f = np.concatenate(hs, 1).astype(np.float64)
+    perm = rng.permutation(B)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    hd = [t(z) for z in zs]
+    scd, shd = [t(a) for a in scs], [t(a) for a in shs]
+    U = t((rng.standard_normal((B, LH)) * 0.05).astype(np.float32))
+    node_off = t(np.arange(B + 1, dtype=np.int32) * n)
+    perm_rows = t(perm.astype(np.int32))
+    hp = (C.c_void_p * L)(*[h.data_ptr() for h in hd])
+    sp = (C.c_void_p * L)(*[scd[l].data_ptr() if given_as_z[l] else None for l in range(L)]) if as_z else None
+    tp = (C.c_void_p * L)(*[shd[l].data_ptr() if given_as_z[l] else None for l in range(L)]) if as_z else None
+    bd = t(np.array([0.3], dtype=np.float32))
+    d_ref = torch.empty(2 * N, device=DEV)
+    check(lib.gnm_disc_score_fwd(hp, sp, tp, H, L, H, U.data_ptr(), LH, perm_rows.data_ptr(), bd.data_ptr(),
+                                 node_off.data_ptr(), N, B, d_ref.data_ptr(), _stream()), "disc fwd")
+    ldunit = (LH + 2 + 3) & ~3
+    unit = torch.full((B, ldunit), float("nan"), device=DEV)
+    inv_perm = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+    d_logit = torch.empty(2 * N, device=DEV)
+    check(lib.gnm_disc_score_fwd_unit(hp, sp, tp, H, L, H, U.data_ptr(), LH, perm_rows.data_ptr(), bd.data_ptr(),
+                                      node_off.data_ptr(), N, B, d_logit.data_ptr(), unit.data_ptr(), ldunit,
+                                      inv_perm.data_ptr(), _stream()), "disc fwd unit")
+    assert torch.equal(d_logit, d_ref)
+    assert np.array_equal(inv_perm.cpu().numpy(), np.argsort(perm).astype(np.int32))
+    # the loss's gradient: dD = k (sigmoid(x) - target), k = upstream * beta / (2N)
+    k = np.float32(1.7) * (np.float32(0.05) / np.float32(2 * N))
+    x64 = d_ref.cpu().numpy().astype(np.float64)
+    tgt = np.concatenate([np.ones(N), np.zeros(N)])
+    dD64 = float(k) * (1.0 / (1.0 + np.exp(-x64)) - tgt)
+    kd = t(np.array([k], dtype=np.float32))
+    dU, s2, dsum = torch.empty((B, LH), device=DEV), torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    check(lib.gnm_disc_unit_scale(unit.data_ptr(), ldunit, LH, kd.data_ptr(), B, dU.data_ptr(), LH, s2.data_ptr(),
+                                  dsum.data_ptr(), _stream()), "unit scale")
+    # (a) against the fp64 statement of the reductions
+    d1, d2 = dD64[:N], dD64[N:]
+    s2_ref = d2.reshape(B, n).sum(1)
+    dU_ref = np.stack([(d1[g * n:(g + 1) * n, None] * n_f[g * n:(g + 1) * n]).sum(0) + s2_ref[g] * n_f[perm[g]]
+                       for g in range(B)])
+    assert_close(s2.cpu().numpy(), s2_ref, rtol=TOL, what="s2sum")
+    assert_close(dsum.cpu().numpy(), s2_ref + d1.reshape(B, n).sum(1), rtol=TOL, what="dsum",
+                 floor=1e-3 * np.abs(dD64).max() * n)
+    assert_close(dU.cpu().numpy(), dU_ref, rtol=TOL, what="dU", floor=1e-3 * np.abs(dU_ref).max())
+    # (b) against the kernel pass it replaces, fed the fp32 gradient a loss kernel would write
+    dDd = t(dD64.astype(np.float32))
+    dU_b, s2_b, dsum_b = torch.empty_like(dU), torch.empty_like(s2), torch.empty_like(dsum)
+    ip_b = torch.empty_like(inv_perm)
+    check(lib.gnm_disc_score_bwd(hp, sp, tp, H, L, H, dDd.data_ptr(), perm_rows.data_ptr(), node_off.data_ptr(), N, B,
+                                 dU_b.data_ptr(), LH, s2_b.data_ptr(), dsum_b.data_ptr(), ip_b.data_ptr(), _stream()),
+          "disc bwd")
+    assert torch.equal(ip_b, inv_perm)
+    assert_close(dU.cpu().numpy(), dU_b.cpu().numpy(), rtol=TOL, what="dU vs pass", floor=1e-3 * np.abs(dU_ref).max())
+    assert_close(s2.cpu().numpy(), s2_b.cpu().numpy(), rtol=TOL, what="s2sum vs pass")
+
+
+def test_discriminator_unit_declines_outside_its_forms():
+    from gnm._cabi import lib
+    B, n, L, H = 2, 8, 3, 20                                    # H / 4 = 5: not a vector form
+    z = [torch.randn(B * n, H, device=DEV) for _ in range(L)]
+    hp = (C.c_void_p * L)(*[h.data_ptr() for h in z])
+    U = torch.randn(B, L * H, device=DEV)
+    node_off = torch.arange(B + 1, dtype=torch.int32, device=DEV) * n
+    perm = torch.arange(B, dtype=torch.int32, device=DEV)
+    d = torch.empty(2 * B * n, device=DEV)
+    unit = torch.empty(B, 64, device=DEV)
+    ip = torch.empty(B, dtype=torch.int32, device=DEV)
+    rc = lib.gnm_disc_score_fwd_unit(hp, None, None, H, L, H, U.data_ptr(), L * H, perm.data_ptr(), None,
+                                     node_off.data_ptr(), B * n, B, d.data_ptr(), unit.data_ptr(), 64, ip.data_ptr(),
+                                     _stream())
+    assert rc == -2
+
+
 @pytest.mark.parametrize("sizes,density", [([40, 40, 40], 0.3), ([37, 5, 64, 1, 23], 0.4), ([400, 400, 400], 0.3),
                                            ([50, 50], 0.0)])
 @pytest.mark.parametrize("average,learn_eps,graph_avg", [(0, 1, 0), (1, 1, 1), (0, 0, 1), (1, 0, 0)])

@@ -247,3 +247,78 @@ def test_fused_loss_gives_the_same_gradients_as_torch_losses():
         flats.append((loss.item(), dp.fp.flat_grad.clone().cpu().numpy()))
     assert abs(flats[0][0] - flats[1][0]) <= 2e-6 * abs(flats[0][0])
     assert rel_err(flats[1][1], flats[0][1]) <= 5e-6
+
+
+@pytest.mark.parametrize("case,scale", [("tiny_s1_eps1_gsum_nsum", 1.0), ("tiny_s1_eps1_gaverage_naverage", -0.7),
+                                        ("true_s0_eps1_gsum_nsum", 1.0)])
+def test_fused_loss_takes_the_discriminator_hand_over(case, scale, monkeypatch):
+    """With gnm.train.infomax_loss (default targets) the model's backward scales the reductions its score kernel left
+    in the forward (gnm/core.py DiscUnit) instead of running gnm_disc_score_bwd's pass over the hidden layers.  Every
+    gradient must equal the route through that pass (the same loss with the hand-over switched off, and torch's own
+    losses as main.py:34-37 writes them) to fp32 rounding, and the pass must really be skipped / really run."""
+    from gnm import core
+    from gnm._cabi import lib
+    from gnm.train import infomax_loss
+    from helpers import load_case
+    from test_gpu_model_parity import make_graphs, make_model
+    cfg, state, d = load_case(case)
+    graphs = make_graphs(cfg, d)
+    labels = torch.tensor([g.label for g in graphs], device=DEV)
+    calls = []
+    real = lib.gnm_disc_score_bwd
+
+    class Spy:
+        def __call__(self, *a):
+            calls.append(1)
+            return real(*a)
+    monkeypatch.setattr(core.lib, "gnm_disc_score_bwd", Spy(), raising=False)
+
+    def run(mode):
+        model = make_model(cfg, state).train()
+        np.random.seed(3)
+        c_logit, d_logit = model(graphs)
+        if mode == "torch":
+            N = d_logit.shape[0] // 2
+            y = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)]).to(DEV)
+            loss = torch.nn.functional.cross_entropy(c_logit, labels) + \
+                0.05 * torch.nn.functional.binary_cross_entropy_with_logits(d_logit, y)
+        else:
+            if mode == "nohold":
+                del d_logit._gnm_disc_unit
+            loss = infomax_loss(c_logit, d_logit, labels, 0.05)[0]
+        n0 = len(calls)
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}, len(calls) - n0
+
+    g_unit, n_unit = run("unit")
+    g_pass, n_pass = run("nohold")
+    g_torch, n_torch = run("torch")
+    assert (n_unit, n_pass, n_torch) == (0, 1, 1)
+    gmax = max(float(np.abs(v).max()) for v in g_pass.values())
+    for name in g_pass:
+        assert rel_err(g_unit[name], g_pass[name], floor=2e-2 * gmax) <= 2e-5, name
+        assert rel_err(g_unit[name], g_torch[name], floor=2e-2 * gmax) <= 2e-5, name
+
+
+def test_discriminator_hand_over_is_not_used_when_the_gradient_was_summed():
+    """d_logit feeding a second consumer: autograd sums two gradients into a new tensor, which is not k (sigmoid - t):
+    the backward must notice (pointer check) and run the general pass."""
+    from gnm.train import infomax_loss
+    from helpers import load_case
+    from test_gpu_model_parity import make_graphs, make_model
+    cfg, state, d = load_case("tiny_s1_eps1_gsum_nsum")
+    graphs = make_graphs(cfg, d)
+    labels = torch.tensor([g.label for g in graphs], device=DEV)
+    res = []
+    for hand_over in (True, False):
+        model = make_model(cfg, state).train()
+        np.random.seed(3)
+        c_logit, d_logit = model(graphs)
+        if not hand_over:
+            del d_logit._gnm_disc_unit
+        loss = infomax_loss(c_logit, d_logit, labels, 0.05)[0] + 1e-3 * d_logit.square().sum()
+        loss.backward()
+        res.append({k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()})
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k          # the same kernels ran: bitwise

@@ -38,6 +38,8 @@ def main():
                     help="random symmetric graphs of --nodes nodes with this edge density instead of the benchmark's "
                          "dense-FC graphs (where does the gather beat the matrix-core kernel?)")
     ap.add_argument("--nodes", type=int, default=400)
+    ap.add_argument("--knn", action="store_true",
+                    help="BASELINE configs[3]: 1000-node kNN (k = 20) graphs; use with --F 128 --batch 256 --pool 256")
     ap.add_argument("--tag", default=os.environ.get("GNM_HIP_LIB", "product"))
     ap.add_argument("--check", action="store_true", help="spot-check the result against a dense fp64 product")
     ap.add_argument("--ab", default=None,
@@ -45,7 +47,9 @@ def main():
                          "launch i of every build before launch i + 1 of any -- clock drift and neighbours hit all alike")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    if args.density is None:
+    if args.knn:
+        pool = synth.make_pool("knn", args.pool, n=1000, f0=7)
+    elif args.density is None:
         pool = synth.make_pool("dense_fc", args.pool)
     else:
         rng0 = np.random.default_rng(1)
@@ -147,7 +151,8 @@ def main():
         else:
             core._agg(batch, x, y, F, eps.data_ptr(), spec, False)
 
-    byt = (4 * 400 * F * 2 + 4 * E + 4 * 401) * args.batch
+    n_nodes = len(pool[0].g)
+    byt = (4 * n_nodes * F * 2 + 4 * E + 4 * (n_nodes + 1)) * args.batch
     for mode in args.modes.split(","):
         for _, L in libs:
             for _ in range(5):

@@ -2,13 +2,14 @@
 # HBM-traffic and SQ counter passes on the aggregation micro-benchmark (separate --pmc passes,
 # counters only with --kernel-trace, as MI355X_MICROARCH.md prescribes).  usage: bash tools/pmc_agg.sh <tag>
 TAG=${1:-x}
-EXTRA=${2:-}      # e.g. --fused
+EXTRA=${2:-}      # modes, e.g. mfused
+ARGS=${3:-}       # extra bench_agg.py arguments, e.g. "--knn --F 128 --batch 256 --pool 256"
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/pmc_agg_$TAG
 mkdir -p $OUT
 run() { name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/tools/bench_agg.py --iters 10 --modes ${EXTRA:-plain} > $OUT/$name.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $R/tools/bench_agg.py --iters 10 --modes ${EXTRA:-plain} $ARGS > $OUT/$name.log 2>&1
   echo "$name exit $?"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
