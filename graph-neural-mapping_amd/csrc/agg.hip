@@ -947,8 +947,8 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
         psc = *reinterpret_cast<const float4*>(p.p_scale + 4 * (tid & 15));
         psh = *reinterpret_cast<const float4*>(p.p_shift + 4 * (tid & 15));
         auto emit = [&](int i, float4 w) {
-            w.x = fmaxf(w.x * psc.x + psh.x, 0.f); w.y = fmaxf(w.y * psc.y + psh.y, 0.f);
-            w.z = fmaxf(w.z * psc.z + psh.z, 0.f); w.w = fmaxf(w.w * psc.w + psh.w, 0.f);
+            w.x = gnm_relu(w.x * psc.x + psh.x); w.y = gnm_relu(w.y * psc.y + psh.y);
+            w.z = gnm_relu(w.z * psc.z + psh.z); w.w = gnm_relu(w.w * psc.w + psh.w);
             if (p.p_hout) *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + (i >> 4)) * p.p_ldh + 4 * (i & 15)) = w;
             csum.x += w.x; csum.y += w.y; csum.z += w.z; csum.w += w.w;
             tile[i] = w;
@@ -1264,8 +1264,8 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 if constexpr (STATS) {
                     if (p.deps_partial && !p.hfwd) {
                         // d eps += dpooled[v] . h[v], h = relu(bn_lo(Z[v])) recomputed as the forward formed it
-                        const float hx = fmaxf(zrow.x * lsc.x + lsh.x, 0.f), hy = fmaxf(zrow.y * lsc.y + lsh.y, 0.f);
-                        const float hz = fmaxf(zrow.z * lsc.z + lsh.z, 0.f), hw = fmaxf(zrow.w * lsc.w + lsh.w, 0.f);
+                        const float hx = gnm_relu(zrow.x * lsc.x + lsh.x), hy = gnm_relu(zrow.y * lsc.y + lsh.y);
+                        const float hz = gnm_relu(zrow.z * lsc.z + lsh.z), hw = gnm_relu(zrow.w * lsc.w + lsh.w);
                         dot += (double)(sb.x * hx + sb.y * hy) + (double)(sb.z * hz + sb.w * hw);
                     }
                 }
@@ -1419,6 +1419,72 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
     return GNM_OK;
 }
 
+// ---- graphs too large for an LDS-resident slice (round 3) ---------------------------------------------------------
+// SURVEY.md 8(d), sparse row: "row-gather from L2/HBM, one wave per destination row".  The kernels above keep a graph's
+// [n, FS] slice in LDS, which bounds n to ~4,500 nodes at the narrowest slice; beyond that (up to the 65,535 nodes the
+// 16-bit column ids allow) this kernel gathers neighbour rows straight from global memory: a workgroup takes 64
+// destination rows of one graph, a wave one row at a time, a lane one column of the current 64-column chunk (4-byte
+// accesses: no alignment demands; a neighbour row's chunk is one 256-byte request).  Same semantics as gnm_agg_kernel
+// (pre / post degree scaling, self loop or (1 + eps) self term, d-eps partial per workgroup in a fixed order); not
+// tuned -- it exists so that no graph the arena can hold is refused.
+static constexpr int kAggGRows = 64;
+__global__ void __launch_bounds__(256) gnm_agg_global_kernel(const AggArgs p, int chunks) {
+    __shared__ double red[4];
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    const int row0 = p.node_off[b];
+    const int n = p.node_off[b + 1] - row0;
+    const int32_t* rp = p.rowptr + p.b_rp_off[b];
+    const uint16_t* cl = p.col + p.b_col_off[b];
+    const int32_t* drp = p.deg_rowptr + p.b_deg_off[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool prescale = p.backward && p.average;
+    const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
+    double dot = 0.0;
+    for (int v = ch * kAggGRows + wave; v < min(n, (ch + 1) * kAggGRows); v += 4) {
+        const int e0 = rp[v], e1 = rp[v + 1];
+        const float dv_in = (float)(drp[v + 1] - drp[v] + p.self_loop);      // what the pre-scale divides row v by
+        for (int c0 = 0; c0 < p.F; c0 += 64) {
+            const int c = c0 + lane;
+            const bool on = c < p.F;
+            float acc = 0.f;
+            for (int e = e0; e < e1; ++e) {
+                const int u = cl[e];
+                float xv = on ? p.x[(size_t)(row0 + u) * p.ldx + c] : 0.f;
+                if (prescale) {           // a row nobody's forward gathered has d = 0 and is never read here
+                    const float du = (float)(drp[u + 1] - drp[u] + p.self_loop);
+                    xv = xv / du;
+                }
+                acc += xv;
+            }
+            const float xs = on ? p.x[(size_t)(row0 + v) * p.ldx + c] : 0.f;
+            const float own = prescale ? xs / dv_in : xs;
+            if (p.deps_partial && on) dot += (double)xs * (double)p.hfwd[(size_t)(row0 + v) * p.ldh + c];
+            if (p.y) {
+                float tot = acc;
+                if (p.self_loop) tot += own;
+                if (p.average && !p.backward) tot /= (float)(e1 - e0 + p.self_loop);   // 0/0 -> NaN as the reference
+                if (!p.self_loop) tot += selfB * xs;
+                if (on) p.y[(size_t)(row0 + v) * p.ldy + c] = tot;
+            }
+        }
+    }
+    if (p.deps_partial) {
+        const double w = wave_sum_d(dot);
+        if (lane == 0) red[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) p.deps_partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+static int agg_global_chunks(int n_max) { return n_max > 0 ? (n_max + kAggGRows - 1) / kAggGRows : 1; }
+
+static int launch_agg_global(const AggArgs& a, int B, int n_max, hipStream_t stream) {
+    const int chunks = agg_global_chunks(n_max);
+    hipLaunchKernelGGL(gnm_agg_global_kernel, dim3((unsigned)B * chunks), dim3(256), 0, stream, a, chunks);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 // Feature-slice width (floats) the launcher will use for width F and the largest
 // graph of the batch; 0 when even the narrowest slice does not fit in LDS.
 extern "C" int gnm_agg_slice_width(int F, int n_max) {
@@ -1437,7 +1503,6 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
     if (B <= 0) return GNM_OK;
     if (F <= 0 || n_max < 0 || n_max > 65535) return GNM_ERR_BAD_ARG;
     const int fs = gnm_agg_slice_width(F, n_max);
-    if (fs == 0) return GNM_ERR_UNSUPPORTED;   // graph too large for an LDS-resident slice
     AggArgs a;
     memset(&a, 0, sizeof(a));
     a.rowptr = rowptr; a.col = col; a.b_rp_off = b_rp_off; a.b_col_off = b_col_off;
@@ -1445,7 +1510,7 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
     a.b_deg_off = b_deg_off ? b_deg_off : b_rp_off;
     a.node_off = node_off; a.x = x; a.y = y; a.eps = eps; a.hfwd = hfwd; a.deps_partial = deps_partial;
     a.ldx = ldx; a.ldy = ldy; a.ldh = ldh; a.F = F;
-    a.nslices = (F + fs - 1) / fs;
+    a.nslices = fs > 0 ? (F + fs - 1) / fs : 1;
     a.average = average; a.self_loop = self_loop; a.backward = backward;
     a.debug = 0;
     a.ids_in_lds = nnz_max > 0 ? nnz_max : 0;   // launch_agg turns this into the 0/1 flag
@@ -1453,6 +1518,10 @@ extern "C" int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t
     a.debug = env_debug;
     if (deps_partial && !hfwd) return GNM_ERR_BAD_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (fs == 0) {              // no slice of this graph fits in LDS: gather from global memory
+        a.nslices = 1;
+        return launch_agg_global(a, B, n_max, s);
+    }
     switch (fs) {
         case 8: return launch_agg<2>(a, B, n_max, s);
         case 16: return launch_agg<4>(a, B, n_max, s);
@@ -1537,6 +1606,6 @@ extern "C" int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, co
 // Number of deps partials gnm_agg writes for (F, n_max, B): B * nslices.
 extern "C" int gnm_agg_num_partials(int F, int n_max, int B) {
     const int fs = gnm_agg_slice_width(F, n_max);
-    if (fs == 0) return 0;
+    if (fs == 0) return B * agg_global_chunks(n_max);      // the global-gather kernel: one partial per workgroup
     return B * ((F + fs - 1) / fs);
 }

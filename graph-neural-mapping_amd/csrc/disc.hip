@@ -25,8 +25,8 @@ __device__ __forceinline__ float gnm_sigmoid(float v) {      // the form of csrc
     return v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
 }
 __device__ __forceinline__ float4 gnm_bnrelu4(float4 x, float4 s, float4 h) {
-    return make_float4(fmaxf(x.x * s.x + h.x, 0.f), fmaxf(x.y * s.y + h.y, 0.f), fmaxf(x.z * s.z + h.z, 0.f),
-                       fmaxf(x.w * s.w + h.w, 0.f));
+    return make_float4(gnm_relu(x.x * s.x + h.x), gnm_relu(x.y * s.y + h.y), gnm_relu(x.z * s.z + h.z),
+                       gnm_relu(x.w * s.w + h.w));
 }
 
 // d_logit[v] = sc_1[v], d_logit[N + v] = sc_2[g(v)]; one workgroup per graph.
@@ -46,7 +46,8 @@ __device__ __forceinline__ float4 gnm_bnrelu4(float4 x, float4 s, float4 h) {
 // into the aggregation-backward epilogues instead: those CONSUME the readout gradient
 // dpool = f(dU W), so all of dU must exist before the first of them runs.
 template <int LPR4, bool UNIT = false>   // lanes per row (H/4), a power of two <= 64; 0 = generic
-__global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, int ldh, int L, int H,
+// (the UNIT form holds ~150 registers: it is always launched with 256 threads)
+__global__ void __launch_bounds__(UNIT ? 256 : 1024) gnm_disc_score_kernel(const HPtrs hp, int ldh, int L, int H,
                                                              const float* __restrict__ U, int ldu,
                                                              const int32_t* __restrict__ perm_rows,
                                                              const float* __restrict__ bias,
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
         for (int l = 0; l < L; ++l)
             for (int c = lane; c < H; c += 64) {
                 float x = hp.p[l][(size_t)pr * ldh + c];
-                if (tmask >> l & 1) x = fmaxf(x * Ss[l * H + c] + Sh[l * H + c], 0.f);
+                if (tmask >> l & 1) x = gnm_relu(x * Ss[l * H + c] + Sh[l * H + c]);
                 a += x * Us[l * H + c];
             }
         a = wave_sum(a);
@@ -219,7 +220,7 @@ __global__ void __launch_bounds__(1024) gnm_disc_score_kernel(const HPtrs hp, in
             for (int l = 0; l < L; ++l)
                 for (int c = lane; c < H; c += 64) {
                     float x = hp.p[l][(size_t)v * ldh + c];
-                    if (tmask >> l & 1) x = fmaxf(x * Ss[l * H + c] + Sh[l * H + c], 0.f);
+                    if (tmask >> l & 1) x = gnm_relu(x * Ss[l * H + c] + Sh[l * H + c]);
                     a += x * Us[l * H + c];
                 }
             a = wave_sum(a);
@@ -249,7 +250,7 @@ static int disc_score_launch(const float* const* hptrs, const float* const* scal
     if (L <= 0 || L > GNM_MAX_LAYERS || H <= 0) return GNM_ERR_BAD_ARG;
     HPtrs hp;
     fill_hptrs(hp, hptrs, scale_ptrs, shift_ptrs, L);
-    const int threads = B >= 1024 ? 256 : 1024;
+    const int threads = (unit || B >= 1024) ? 256 : 1024;
     size_t lds = (size_t)(3 * L * H + 4) * 4;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const bool vec = ((ldh & 3) == 0) && ((H & 3) == 0);

@@ -48,6 +48,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 static constexpr int kWave = 64;           // CDNA wavefront
 static constexpr int kLdsBudget = 160 * 1024;  // bytes of LDS per CU (gfx950)
 
+// ReLU the way torch computes it (graphcnn.py:166 / :190, mlp.py:48): a NaN stays a NaN, where fmaxf(x, 0) would
+// return 0 (IEEE maxNum) and quietly repair a poisoned row -- e.g. the 0/0 row of an isolated node under neighbour
+// "average" + learn_eps (graphcnn.py:157-158), which in the reference makes that graph's readout and logits NaN.
+// One instruction on gfx950 (v_maximum3_f32, IEEE-754-2019 maximum).
+__device__ __forceinline__ float gnm_relu(float x) { return __builtin_elementwise_maximum(x, 0.f); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(256) gnm_lin_kernel(const LinArgs p) {
                         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
                         v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                         if (p.pro_relu) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                            v.x = gnm_relu(v.x); v.y = gnm_relu(v.y);
+                            v.z = gnm_relu(v.z); v.w = gnm_relu(v.w);
                         }
                     }
                 }
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
                     float4 v = raw[j];
                     v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                     if (p.pro_relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        v.x = gnm_relu(v.x); v.y = gnm_relu(v.y); v.z = gnm_relu(v.z); v.w = gnm_relu(v.w);
                     }
                     raw[j] = v;
                 }
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(256) gnm_lin_stream_kernel(const LinArgs p) {
             if (pro) {
                 v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                 if (p.pro_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    v.x = gnm_relu(v.x); v.y = gnm_relu(v.y); v.z = gnm_relu(v.z); v.w = gnm_relu(v.w);
                 }
             }
             *reinterpret_cast<float4*>(Xs + (lrow0 + j * RSTEP) * XS + 4 * c4) = v;
@@ -814,7 +814,7 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
             if (pro) {
                 v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                 if (p.pro_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    v.x = gnm_relu(v.x); v.y = gnm_relu(v.y); v.z = gnm_relu(v.z); v.w = gnm_relu(v.w);
                 }
             }
             *reinterpret_cast<float4*>(Xs + (lrow0 + j * RSTEP) * XS + 4 * c4) = v;
@@ -1115,7 +1115,7 @@ __global__ void __launch_bounds__(256) gnm_wgrad_kernel(const WgArgs p) {
                 x = p.X[(size_t)n * p.ldx + kcol[b]];
                 if (p.pro_scale) {
                     x = x * sc[b] + sh[b];
-                    if (p.pro_relu) x = fmaxf(x, 0.f);
+                    if (p.pro_relu) x = gnm_relu(x);
                 }
             }
             bv[b] = x;
@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(256) gnm_wgrad_fast_kernel(const WgArgs p) {
                 float x = bv[u][b];
                 if (p.pro_scale) {
                     x = x * sc[b] + sh[b];
-                    if (p.pro_relu) x = fmaxf(x, 0.f);
+                    if (p.pro_relu) x = gnm_relu(x);
                 }
                 bv[u][b] = (rok && kok[b]) ? x : 0.f;
             }
@@ -1606,7 +1606,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
                 float x = xv[s][b];
                 if (p.pro_scale) {
                     x = x * psc[b] + psh[b];
-                    if (p.pro_relu) x = fmaxf(x, 0.f);
+                    if (p.pro_relu) x = gnm_relu(x);
                     if (NARROW && !(32 * b + i < p.K)) x = 0.f;      // padding columns stay zero
                 }
                 xf[b] = x;                                          // (SAMEZ keeps the raw Z in xv for the epilogue)
@@ -1979,7 +1979,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
                 float x = xv[s][b];
                 if (p.pro_scale) {
                     x = x * psc[b] + psh[b];
-                    if (p.pro_relu) x = fmaxf(x, 0.f);
+                    if (p.pro_relu) x = gnm_relu(x);
                 }
                 xf[b] = x;
             }

@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(1024) gnm_bn_relu_readout_kernel(
             float4 v = *reinterpret_cast<const float4*>(Z + (size_t)(row0 + r) * ldz + 4 * c4);
             v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
             if (relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                v.x = gnm_relu(v.x); v.y = gnm_relu(v.y); v.z = gnm_relu(v.z); v.w = gnm_relu(v.w);
             }
             if (Hout) *reinterpret_cast<float4*>(Hout + (size_t)(row0 + r) * ldh + 4 * c4) = v;   // (kernel-uniform)
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;

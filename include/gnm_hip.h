@@ -113,10 +113,13 @@ int gnm_sum_partials(const double* partial, int count, float* out, void* stream)
  * The same three operations over a BIT adjacency: y = A x as MFMA products of the 0/1 matrix with three bf16 planes
  * of x (x split by truncation, every product exact: fp32-faithful like the gather).  Pays when the graphs are dense
  * (the 400-node benchmark graphs are 30 % dense: ~3x the gather); the caller chooses per batch.
- * Bit matrix of one graph with n nodes: W = ceil(n / 32) words of bits per row, stored with a row stride of WP = W
- * rounded up to a multiple of 4 words (16-byte rows), 32 W rows (zero rows pad the last block); bit (k % 32) of word
- * [v][k / 32] = 1 iff k is a neighbour in row v of that graph's CSR: gnm_adj_bits_words(n) = 32 W WP words at
- * adj_bits + b_bits_off[b] (adj_bits 16-byte aligned, offsets multiples of 4 words).  Built on the device from the arena's CSR by gnm_adj_bits_build, which also
+ * Bit matrix of one graph with n nodes: W = ceil(n / 32) words = 4 W bytes of bits per row; bit (k % 8) of byte k / 8
+ * = 1 iff k is a neighbour in row v of that graph's CSR.  A row's bytes are stored DE-INTERLEAVED (round 3): byte j in
+ * half (j & 1) of the row at position (j >> 1) -- the even bytes are what lanes 0-31 of an MFMA step multiply, the odd
+ * ones lanes 32-63, so a lane loads exactly its bytes -- each half padded with zeros to HP = ceil(W / 2) rounded up to 4
+ * words; a row is 2 HP words and there are 32 W rows (zero rows pad the last block): gnm_adj_bits_words(n) = 64 W HP
+ * words at adj_bits + b_bits_off[b] (adj_bits 16-byte aligned, offsets multiples of 4 words).  Built on the device from
+ * the arena's CSR by gnm_adj_bits_build, which also
  * counts, per graph, CSR entries that repeat an edge (dup[g] > 0: a multigraph -- the bit matrix cannot carry the
  * multiplicity, keep that graph on gnm_agg).  Pass the bit matrix of the TRANSPOSED CSR for backward = 1.
  * All other arguments: exactly as in gnm_agg / gnm_agg_bwd_stats / gnm_agg_fwd_bnrelu (rowptr and the offsets are
@@ -126,6 +129,13 @@ int gnm_sum_partials(const double* partial, int count, float* out, void* stream)
 long long gnm_adj_bits_words(int n);
 int gnm_aggm_max_nodes(void);
 int gnm_aggm_num_partials(int F, int B);
+/* Launches of at least this many units (graphs x 32-column blocks; F >= 32, n_max <= 400) run as ONE persistent
+ * workgroup per CU -- 3 loader waves streaming and splitting the next unit's tile into a second LDS plane buffer while
+ * 13 compute waves multiply the current one (csrc/aggm.hip, gnm_aggp_kernel) -- instead of a workgroup per unit.  Same
+ * results to fp32 rounding, same fixed reduction orders.  v >= 0 sets the threshold (1 = always, a huge value = never),
+ * v < 0 only reads it; returns the previous value.  Initial value: environment GNM_AGGP_MIN_UNITS, else never (1 << 30):
+ * measured slower than the per-unit kernel at B = 1024 (profiles/r03_aggp_timeline.md). */
+int gnm_aggm_persistent_min_units(int v);
 int gnm_adj_bits_build(const int32_t* rowptr, const uint16_t* col, const int64_t* g_rp_off, const int64_t* g_col_off,
                        const int32_t* g_n, int G, uint32_t* bits, const int64_t* g_bits_off, int32_t* dup,
                        void* stream);

@@ -18,6 +18,17 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+@pytest.fixture(params=["per_unit", "persistent"], autouse=True)
+def aggm_kernel_form(request):
+    """every test of this file runs through both forms of the matrix-core kernel: a workgroup per (graph, column
+    block), and the persistent one-workgroup-per-CU form with loader and compute waves (gnm_aggp_kernel; shapes it does
+    not cover -- n_max > 400, F < 32 -- take the per-unit kernel either way)"""
+    from gnm._cabi import lib
+    old = lib.gnm_aggm_persistent_min_units(1 if request.param == "persistent" else 1 << 30)
+    yield request.param
+    lib.gnm_aggm_persistent_min_units(old)
+
+
 def test_bit_adjacency_matches_the_csr():
     from gnm._cabi import lib
     from gnm.arena import GraphArena
@@ -38,16 +49,20 @@ def test_bit_adjacency_matches_the_csr():
             assert not ar.bits_ok[gid]
             continue
         W = (n + 31) // 32
-        WP = (W + 3) // 4 * 4
-        assert lib.gnm_adj_bits_words(n) == W * 32 * WP
+        HP = ((W + 1) // 2 + 3) // 4 * 4                                   # words per half row (include/gnm_hip.h)
+        assert lib.gnm_adj_bits_words(n) == W * 32 * 2 * HP
         A = np.zeros((n, n), dtype=bool)
         e = g.edge_mat.numpy()
         A[e[0], e[1]] = True
         for off, M in ((ar.bits_off[gid], A), (ar.t_bits_off[gid], A.T)):
-            w = bits[off:off + W * 32 * WP].reshape(32 * W, WP)
-            assert not w[:, W:].any()                                       # padding words stay zero
-            w = w[:, :W]
-            got = ((w[:, :, None] >> np.arange(32, dtype=np.uint32)[None, None, :]) & 1).astype(bool).reshape(32 * W, 32 * W)
+            w = bits[off:off + W * 32 * 2 * HP].reshape(32 * W, 2 * HP)
+            by = w.view(np.uint8).reshape(32 * W, 2, 4 * HP)                # [row][half][position]
+            nb = 4 * W                                                      # bytes of a row: byte j -> half j & 1, position j >> 1
+            rowbytes = np.zeros((32 * W, nb), dtype=np.uint8)
+            rowbytes[:, 0::2] = by[:, 0, :(nb + 1) // 2]
+            rowbytes[:, 1::2] = by[:, 1, :nb // 2]
+            assert not by[:, 0, (nb + 1) // 2:].any() and not by[:, 1, nb // 2:].any()     # padding stays zero
+            got = np.unpackbits(rowbytes, axis=1, bitorder="little").astype(bool)           # [32 W, 32 W]
             assert np.array_equal(got[:n, :n], M)
             assert not got[n:].any() and not got[:, n:].any()             # padding rows / bits stay zero
         assert ar.bits_ok[gid] == (k != len(graphs) - 2)                   # only the multigraph is refused
@@ -67,6 +82,8 @@ AGGM_CASES = [
     ([300, 130], 0.15, 128, True),           # four column blocks
     ([45, 45, 45], 0.3, 64, False),          # asymmetric: backward runs on the transposed bit matrix
     ([17] * 11, 0.5, 64, True),              # more graphs than one XCD round
+    ([17] * 300 + [33, 1, 64], 0.5, 64, True),   # 606 units: the persistent form walks 2-3 units per workgroup
+    ([40] * 700, 0.3, 64, True),             # 1,400 units: 5-6 per workgroup, both plane buffers many times over
     ([400, 400], 0.3, 7, True),              # the input layer: one partial column block, unaligned rows
     ([37, 5, 64, 1, 23], 0.4, 5, True),
     ([45, 45, 45], 0.3, 20, False),

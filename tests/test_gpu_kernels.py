@@ -593,7 +593,8 @@ def test_discriminator_scores_vs_literal_bilinear(B, n, L, H, as_z):
                                      (3, 40, 4, 128)])
 @pytest.mark.parametrize("as_z", [False, True])
 def test_discriminator_unit_reductions_equal_the_backward_pass(B, n, L, H, as_z):
-    """gnm_disc_score_fwd_unit: same d_logit as gnm_disc_score_fwd (bitwise: same kernel body), and its by-products,
+    """gnm_disc_score_fwd_unit: same d_logit as gnm_disc_score_fwd (to fp32 rounding: the two instantiations of the
+    kernel body contract their multiply-adds differently), and its by-products,
     scaled by gnm_disc_unit_scale, are what gnm_disc_score_bwd computes from dD = k (sigmoid(d_logit) - target) -- the
     gradient of beta * BCEWithLogits against ones / zeros (main.py:32-37) -- and what fp64 says.  (1100 graphs: the
     256-thread workgroup form; 3 graphs: 1024 threads.)"""
@@ -627,7 +628,7 @@ def test_discriminator_unit_reductions_equal_the_backward_pass(B, n, L, H, as_z)
     check(lib.gnm_disc_score_fwd_unit(hp, sp, tp, H, L, H, U.data_ptr(), LH, perm_rows.data_ptr(), bd.data_ptr(),
                                       node_off.data_ptr(), N, B, d_logit.data_ptr(), unit.data_ptr(), ldunit,
                                       inv_perm.data_ptr(), _stream()), "disc fwd unit")
-    assert torch.equal(d_logit, d_ref)
+    assert_close(d_logit.cpu().numpy(), d_ref.cpu().numpy().astype(np.float64), rtol=2e-6, what="d_logit (unit form)")
     assert np.array_equal(inv_perm.cpu().numpy(), np.argsort(perm).astype(np.int32))
     # the loss's gradient: dD = k (sigmoid(x) - target), k = upstream * beta / (2N)
     k = np.float32(1.7) * (np.float32(0.05) / np.float32(2 * N))
@@ -947,3 +948,67 @@ def test_linear_kernels_many_tiles_per_wave(N):
         assert_close(dW.cpu().numpy(), (dZ.t() @ Xin).cpu().numpy(), rtol=5e-5, what=form + ": dW")
         assert_close(db.cpu().numpy(), dZ.sum(0).cpu().numpy(), rtol=5e-5, what=form + ": db",
                      floor=1e-2 * float(dZ.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize("average,learn_eps", [(0, 1), (1, 1), (0, 0), (1, 0)])
+@pytest.mark.parametrize("F", [16, 64, 7])
+def test_aggregation_of_graphs_too_large_for_lds(average, learn_eps, F):
+    """Graphs beyond ~4,500 nodes have no LDS-resident slice: gnm_agg gathers their neighbour rows from global memory
+    (gnm_agg_global_kernel; SURVEY.md 8(d), sparse row) instead of refusing them.  Forward, backward (transposed
+    structure of an asymmetric graph) and the d-eps partials against the fp64 restatement of graphcnn.py:154-161 /
+    178-182; mixed with a small graph in the same batch (n_max decides the kernel for the whole launch)."""
+    from gnm import core
+    from gnm._cabi import lib
+    from gnm.arena import GraphArena
+    rng = np.random.default_rng(F * 10 + average)
+    n_big = 6000
+    assert lib.gnm_agg_slice_width(F, n_big) == 0
+    src = rng.integers(0, n_big, 30000)
+    dst = rng.integers(0, n_big, 30000)
+    keep = src != dst
+    em = np.unique(np.stack([src[keep], dst[keep]]), axis=1)            # asymmetric, no repeated edges
+    graphs = [RG(n_big, em, 3, rng)] + random_graphs(rng, [50], 0.2, False)
+    ar = GraphArena(DEV)
+    batch = ar.batch(graphs)
+    assert not batch.dense and not batch.symmetric
+    A = dense_adj(graphs)
+    N = batch.N
+    deg = np.asarray(A.sum(1)).reshape(-1, 1)
+    x = rng.standard_normal((N, F)).astype(np.float32)
+    eps = 0.37
+    spec = core.GinSpec(1, 1, bool(learn_eps), "sum", "average" if average else "sum")
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.full((N, F), float("nan"), device=DEV)
+    epsd = torch.tensor([eps], device=DEV)
+    core._agg(batch, xd, yd, F, epsd.data_ptr() if learn_eps else None, spec, backward=False)
+    x64 = x.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if learn_eps:
+            ref = A @ x64
+            if average:
+                ref = ref / deg
+            ref = ref + (1 + np.float32(eps).astype(np.float64)) * x64
+        else:
+            ref = (A @ x64 + x64) / ((deg + 1) if average else 1.0)
+    assert_close(yd.cpu().numpy(), ref, rtol=TOL, what="global gather forward")
+    # backward: d h = A^T (d pooled [/ deg]) + self term; d eps partial = sum d pooled . h
+    dp = rng.standard_normal((N, F)).astype(np.float32)
+    dpd = torch.from_numpy(dp).to(DEV)
+    dhd = torch.full((N, F), float("nan"), device=DEV)
+    part = torch.full((core.agg_partials_capacity(batch, F),), float("nan"), dtype=torch.float64, device=DEV)
+    cnt = core._agg(batch, dpd, dhd, F, epsd.data_ptr() if learn_eps else None, spec, backward=True,
+                    hfwd=xd if learn_eps else None, deps_partial=part if learn_eps else None)
+    dp64 = dp.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if learn_eps:
+            g = dp64 / deg if average else dp64
+            g = np.where(deg > 0, g, 0.0) if average else g
+            ref_b = A.T @ g + (1 + np.float32(eps).astype(np.float64)) * dp64
+        else:
+            g = dp64 / (deg + 1) if average else dp64
+            ref_b = A.T @ g + g
+    assert_close(dhd.cpu().numpy(), ref_b, rtol=TOL, what="global gather backward")
+    if learn_eps:
+        assert cnt == lib.gnm_agg_num_partials(F, batch.n_max, batch.B) > 0
+        want = float((dp64 * x64).sum())
+        assert abs(float(part[:cnt].sum().item()) - want) <= 1e-6 * float(np.abs(dp64 * x64).sum())

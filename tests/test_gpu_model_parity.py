@@ -289,9 +289,12 @@ def test_isolated_node_average_nan_matches_reference():
     core.encoder_forward = wrapped
     try:
         with torch.no_grad():
-            model(graphs)
+            c_logit, d_logit = model(graphs)
     finally:
         core.encoder_forward = orig
+    # the reference's ReLU keeps a NaN (torch.relu), so the poisoned row reaches the graph's readout and BOTH outputs of
+    # that graph are NaN -- fmaxf(x, 0) would quietly return 0 there (csrc/gnm_common.h gnm_relu)
+    assert torch.isnan(c_logit).all() and torch.isnan(d_logit).all()
     assert np.isnan(store["pooled"][0][3]).all()
     assert not np.isnan(store["pooled"][0][0]).any()
     # every layer, not only the first: the reference keeps the NaN to the isolated node's own row (nobody gathers
