@@ -156,3 +156,128 @@ class CapturedEval:
             self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
         self.graph.replay()
         return self.c_logit, self.d_logit, self.g_f
+
+
+class CapturedTrain:
+    """GIN_InfoMaxReg.forward of B equal-size graphs in TRAIN mode, and its backward, as two replayed hipGraphs -- for a
+    caller that is the reference's own loop (main.py:19-47: model(batch_graph); torch losses; optimizer.zero_grad();
+    loss.backward(); optimizer.step(), batch 32 by default), which this package cannot change.  Eagerly such a step is
+    ~200 launches from Python (~2 ms of host time for ~0.5 ms of GPU work at B = 32); replayed it is two graph launches
+    plus the caller's own loss and optimizer.
+
+    Forward graph: the kernels of GinInfoMaxFn.forward on static batch descriptors (incl. BatchNorm running-statistics
+    updates and the dropout masks, whose Philox state torch advances per replay).  Backward graph:
+    torch.autograd.grad of the captured outputs against two static gradient buffers.  The gradients come back as views
+    of static buffers; models/graphcnn.py hands them to autograd, which -- after the usual zero_grad(set_to_none) --
+    adopts them as .grad without a copy.
+
+    Everything shape-like is frozen: B, n, symmetry / density class, the parameters' addresses.  One forward may be
+    outstanding per capture (its activations live in the graph's pool); models/graphcnn.py falls back to the eager
+    path for anything else."""
+
+    def __init__(self, model, gids_host, warmup=2):
+        arena = model.arena()
+        tb = arena._tables()
+        gh = np.asarray(gids_host, dtype=np.int64)
+        n = int(tb["n_host"][gh[0]])
+        if not (tb["n_host"][gh] == n).all():
+            raise ValueError("CapturedTrain needs equal-size graphs (as the discriminator does, discriminator.py:24)")
+        nnz = int(tb["nnz_host"][gh].max())
+        nnz_cap = max(4096, 1 << (nnz - 1).bit_length()) if nnz > 0 else 4096
+        self.model = model
+        self.static = PackedStaticBatch(arena, gh.shape[0], n, bool(tb["sym_host"][gh].all()), nnz_cap,
+                                        dense=arena.dense_ok(gh), iso=bool(tb["iso_host"][gh].any()))
+        self.static.load_gids(gh)
+        dev = arena.device
+        B = gh.shape[0]
+        # a PERMUTATION from the start: the warm-up passes run the backward, whose shuffled-branch term indexes by the
+        # inverse permutation (zeros here left it mostly unwritten -> wild reads: a GPU memory fault in the first version)
+        self.perm = torch.arange(B, dtype=torch.int32, device=dev)
+        self._params = [p for p in model.parameters()]
+        self._req = [p for p in self._params if p.requires_grad]
+        self._tracked = self._params + [b for b in model.buffers()]
+        self._ptrs = tuple(t.data_ptr() for t in self._tracked)
+        self._req_mask = tuple(p.requires_grad for p in self._params)
+        self.outstanding = None        # weak reference to the outputs of a replayed forward that has not been backpropagated
+        keep = [b for b in model.buffers()]                # BatchNorm statistics: the warm-up passes must not count
+        snapshot = [t.clone() for t in keep]
+        sink, model._spec.grad_sink = model._spec.grad_sink, None     # plain autograd gradients inside the capture
+        try:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    c, d, _ = self._forward()
+                    torch.autograd.grad((c, d), self._req, (torch.zeros_like(c), torch.zeros_like(d)), allow_unused=True)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            self.fwd_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.fwd_graph, capture_error_mode="thread_local"):
+                self.c_logit, self.d_logit, _ = self._forward()
+            self.dC = torch.zeros_like(self.c_logit)
+            self.dD = torch.zeros_like(self.d_logit)
+            self.bwd_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), capture_error_mode="thread_local"):
+                self.grads = torch.autograd.grad((self.c_logit, self.d_logit), self._req, (self.dC, self.dD),
+                                                 allow_unused=True)
+        finally:
+            model._spec.grad_sink = sink
+        with torch.no_grad():
+            for t, s0 in zip(keep, snapshot):
+                t.copy_(s0)
+        torch.cuda.synchronize(dev)
+        self._arena_ptrs = self._arena_buffers()
+        self._grad_ptrs = frozenset(g.data_ptr() for g in self.grads if g is not None)
+
+    _arena_buffers = CapturedEval._arena_buffers
+
+    def _forward(self):
+        m = self.model
+        bt = self.static.batch
+        X, P0 = bt.arena.features_and_agg0(bt, m._spec.n_avg, not m._spec.learn_eps)
+        return m._run(bt, X, self.perm, want_disc=True, P0=P0, hand_over=False)
+
+    def valid_for(self, gh):
+        m = self.model
+        return (self.static.fits(gh) and self._arena_buffers() == self._arena_ptrs
+                and tuple(t.data_ptr() for t in self._tracked) == self._ptrs
+                and tuple(p.requires_grad for p in self._params) == self._req_mask
+                and m._spec.grad_sink is None and m._spec.sync_bn is None)
+
+    def busy(self):
+        """a replayed forward whose outputs are still alive and not yet backpropagated owns the captured activations"""
+        o = self.outstanding
+        return o is not None and o() is not None
+
+    def forward(self, gh, perm):
+        self.static.load_gids(gh)
+        if self.static.B > 1:
+            self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
+        self.fwd_graph.replay()
+        return self.c_logit, self.d_logit
+
+    def backward(self, dC, dD):
+        """replays the backward on the outstanding forward; returns one gradient per parameter (None where unused) as
+        FRESH views of the static buffers (a tensor nobody else references is what autograd may adopt as .grad)"""
+        # a .grad that still aliases one of the static buffers (adopted last step and not cleared: gradient
+        # accumulation) must own its values before the replay overwrites them
+        for p in self._req:
+            g = p.grad
+            if g is not None and g.data_ptr() in self._grad_ptrs:
+                p.grad = g.clone()
+        if dC is None:
+            self.dC.zero_()
+        else:
+            self.dC.copy_(dC)
+        if dD is None:
+            self.dD.zero_()
+        else:
+            self.dD.copy_(dD)
+        self.bwd_graph.replay()
+        self.outstanding = None
+        it = iter(self.grads)
+        out = []
+        for p in self._params:
+            g = next(it) if p.requires_grad else None
+            out.append(g.view_as(g) if g is not None else None)
+        return out

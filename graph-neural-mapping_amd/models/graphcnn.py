@@ -70,6 +70,23 @@ class _LazyEvalGrad(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(next(it) if t.requires_grad else None for t in tensors)
 
 
+class _TrainReplayFn(torch.autograd.Function):
+    """A train-mode forward replayed from a captured hipGraph (gnm/graphs.py CapturedTrain), attached to the parameters
+    so that the caller's loss.backward() replays the captured backward.  Outputs are copies (the static buffers belong
+    to the next replay)."""
+
+    @staticmethod
+    def forward(ctx, cap, gh, perm, *params):
+        c_logit, d_logit = cap.forward(gh, perm)
+        ctx.cap = cap
+        ctx.set_materialize_grads(False)
+        return c_logit.clone(), d_logit.clone()
+
+    @staticmethod
+    def backward(ctx, dC, dD):
+        return (None, None, None) + tuple(ctx.cap.backward(dC, dD))
+
+
 class GIN_InfoMaxReg(nn.Module):
     def __init__(self, num_layers, num_mlp_layers, input_dim, hidden_dim, output_dim, final_dropout, learn_eps,
                  graph_pooling_type, neighbor_pooling_type, device):
@@ -101,6 +118,11 @@ class GIN_InfoMaxReg(nn.Module):
         # {(B, n): CapturedEval}, a few entries; eval_replay = False turns it off
         self.eval_replay = True
         self._eval_cache = {}
+        # train-mode forwards (and their backwards) of small batches are replayed too (gnm/graphs.py CapturedTrain):
+        # what makes the reference's own loop (main.py:19-47, batch 32) GPU-bound instead of launch-bound.
+        # train_replay = False turns it off
+        self.train_replay = True
+        self._train_cache = {}
 
     @staticmethod
     def _check_kernel_limits(num_layers, input_dim, hidden_dim):
@@ -130,6 +152,7 @@ class GIN_InfoMaxReg(nn.Module):
         # .to() / .cuda() / .float() may replace buffer tensors: drop the cached lists and captured graphs
         self._plist = None
         self._eval_cache = {}
+        self._train_cache = {}
         return super()._apply(fn, *args, **kwargs)
 
     def _param_lists(self):
@@ -141,10 +164,10 @@ class GIN_InfoMaxReg(nn.Module):
             pl = self._plist = (names, tensors, dict(self.named_buffers()))
         return pl
 
-    def _run(self, batch, X, perm, want_disc, P0=None):
+    def _run(self, batch, X, perm, want_disc, P0=None, hand_over=True):
         names, tensors, buffers = self._param_lists()
         hold = None
-        if want_disc and self.training and DISC_UNIT and torch.is_grad_enabled():
+        if want_disc and self.training and DISC_UNIT and hand_over and torch.is_grad_enabled():
             # let the score kernel leave the backward's reductions for the reference's BCE loss (gnm/core.py DiscUnit);
             # only a loss that recognises the hand-over on d_logit (gnm.train.infomax_loss) makes use of it
             hold = want_disc = DiscUnit()
@@ -238,6 +261,53 @@ class GIN_InfoMaxReg(nn.Module):
             return _LazyEvalGrad.apply(self, gh, perm, c_logit, d_logit, *tensors)
         return c_logit, d_logit
 
+    # ------------------------------------------------------------------ training replay
+    TRAIN_REPLAY_MAX_B = 128        # beyond this a step is GPU-bound from Python too (and activations get large)
+    TRAIN_REPLAY_ENTRIES = 3
+
+    def _forward_train_replay(self, batch_graph):
+        """forward() in train mode for a small batch of equal-size graphs: forward and backward replayed from captured
+        hipGraphs (same kernels, same order as the eager path).  None when the batch does not qualify -- other shapes,
+        a forward still outstanding on the capture, a gradient sink / cross-rank BatchNorm installed, parameters that
+        moved -- and the caller then takes the eager path."""
+        arena = self.arena()
+        sp = self._spec
+        if arena.device.type != "cuda" or sp.grad_sink is not None or sp.sync_bn is not None or sp.keep_hidden:
+            return None
+        gh = np.asarray(arena.add_many(batch_graph), dtype=np.int64)
+        tb = arena._tables()
+        n = int(tb["n_host"][gh[0]])
+        B = int(gh.shape[0])
+        if not (tb["n_host"][gh] == n).all():
+            return None
+        from gnm.graphs import CapturedTrain
+        arena.refresh_agg0(sp.n_avg, not sp.learn_eps)
+        key = (B, n)
+        ct = self._train_cache.get(key)
+        if ct is not None and ct.busy():
+            return None                                   # its activations belong to a forward not yet backpropagated
+        if ct is None or not ct.valid_for(gh):
+            if len(self._train_cache) >= self.TRAIN_REPLAY_ENTRIES and key not in self._train_cache:
+                self._train_cache.pop(next(iter(self._train_cache)))
+            rng_state = np.random.get_state()
+            try:
+                with torch.cuda.device(arena.device):
+                    ct = self._train_cache[key] = CapturedTrain(self, gh)
+            except Exception as e:          # e.g. a hook that synchronises inside the forward: stay eager
+                import warnings
+                warnings.warn("train-mode hipGraph capture failed (%s: %s); training eagerly from now on"
+                              % (type(e).__name__, e))
+                self.train_replay = False
+                self._train_cache.pop(key, None)
+                np.random.set_state(rng_state)
+                return None
+        perm = np.random.permutation(B)                                       # graphcnn.py:199, consumed as always
+        names, tensors, _ = self._param_lists()
+        c_logit, d_logit = _TrainReplayFn.apply(ct, gh, perm, *tensors)
+        import weakref
+        ct.outstanding = weakref.ref(c_logit)
+        return c_logit, d_logit
+
     # ------------------------------------------------------------------ reference API
     def _batch_of(self, batch_graph):
         batch = self.arena().batch(batch_graph)
@@ -250,6 +320,11 @@ class GIN_InfoMaxReg(nn.Module):
         if (not self.training and self.eval_replay and not self._spec.n_max
                 and 0 < len(batch_graph) <= self.EVAL_REPLAY_MAX_B):
             out = self._forward_eval_replay(batch_graph, latent)
+            if out is not None:
+                return out
+        if (self.training and self.train_replay and not latent and not self._spec.n_max and torch.is_grad_enabled()
+                and 0 < len(batch_graph) <= self.TRAIN_REPLAY_MAX_B):
+            out = self._forward_train_replay(batch_graph)
             if out is not None:
                 return out
         return self.forward_batch(self._batch_of(batch_graph), latent=latent)

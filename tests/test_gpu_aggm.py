@@ -18,15 +18,18 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-@pytest.fixture(params=["per_unit", "persistent"], autouse=True)
+@pytest.fixture(params=["per_unit", "persistent", "persistent2"], autouse=True)
 def aggm_kernel_form(request):
     """every test of this file runs through both forms of the matrix-core kernel: a workgroup per (graph, column
     block), and the persistent one-workgroup-per-CU form with loader and compute waves (gnm_aggp_kernel; shapes it does
-    not cover -- n_max > 400, F < 32 -- take the per-unit kernel either way)"""
+    not cover -- n_max > 400, F < 32 -- take the per-unit kernel either way), and the two-workgroups-per-CU persistent
+    form with the next tile held in registers (gnm_aggq_kernel)"""
     from gnm._cabi import lib
-    old = lib.gnm_aggm_persistent_min_units(1 if request.param == "persistent" else 1 << 30)
+    old = lib.gnm_aggm_persistent_min_units(1 if request.param != "per_unit" else 1 << 30)
+    old_form = lib.gnm_aggm_persistent_form(2 if request.param == "persistent2" else 1)
     yield request.param
     lib.gnm_aggm_persistent_min_units(old)
+    lib.gnm_aggm_persistent_form(old_form)
 
 
 def test_bit_adjacency_matches_the_csr():

@@ -1,0 +1,114 @@
+"""Train-mode forwards and backwards replayed from captured hipGraphs inside an UNCHANGED reference-style loop
+(models/graphcnn.py _forward_train_replay, gnm/graphs.py CapturedTrain; main.py:19-47): same kernels in the same order
+as the eager path, so everything is bitwise equal to it."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_training_loop import make_task
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(dropout=0.0, replay=True, seed=0):
+    from models.graphcnn import GIN_InfoMaxReg
+    dev = torch.device(DEV)
+    torch.manual_seed(seed)
+    model = GIN_InfoMaxReg(3, 2, 7, 32, 2, dropout, True, "sum", "average", dev).to(dev).train()
+    model.train_replay = replay
+    return model
+
+
+def loop(model, graphs, steps, zero_every=1, batch_size=8):
+    """the reference's train() body (main.py:24-41) with torch's own losses and optimizer"""
+    dev = torch.device(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01)
+    ce, bce = torch.nn.CrossEntropyLoss(), torch.nn.BCEWithLogitsLoss()
+    n = len(graphs[0].g)
+    rng = np.random.default_rng(5)
+    np.random.seed(11)
+    trace = []
+    for s in range(steps):
+        batch = [graphs[i] for i in rng.permutation(len(graphs))[:batch_size]]
+        c_logit, d_logit = model(batch)
+        lab = torch.LongTensor([g.label for g in batch]).to(dev)
+        d_lab = torch.cat([torch.ones(batch_size * n, 1), torch.zeros(batch_size * n, 1)], 0).to(dev)
+        loss = ce(c_logit, lab) + 0.05 * bce(d_logit, d_lab)
+        if s % zero_every == 0:
+            opt.zero_grad()
+        loss.backward()
+        trace.append((c_logit.detach().clone(), d_logit.detach().clone(),
+                      [p.grad.detach().clone() for p in model.parameters() if p.grad is not None]))
+        if s % zero_every == zero_every - 1:
+            opt.step()
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return trace, state
+
+
+@pytest.mark.parametrize("zero_every", [1, 2])
+def test_replayed_training_equals_eager_bitwise(zero_every):
+    """zero_every = 2: gradients accumulate over two backward passes before a step -- the .grad tensors autograd
+    adopted from the static buffers must not be clobbered by the next replay."""
+    graphs = make_task(24)
+    a_trace, a_state = loop(build(replay=False), graphs, 6, zero_every)
+    model = build(replay=True)
+    b_trace, b_state = loop(model, graphs, 6, zero_every)
+    assert len(model._train_cache) == 1 and not model._eval_cache
+    for s, ((c0, d0, g0), (c1, d1, g1)) in enumerate(zip(a_trace, b_trace)):
+        assert torch.equal(c0, c1) and torch.equal(d0, d1), "outputs differ at step %d" % s
+        assert len(g0) == len(g1)
+        for x, y in zip(g0, g1):
+            assert torch.equal(x, y), "gradient differs at step %d" % s
+    for k in a_state:
+        assert torch.equal(a_state[k], b_state[k]), k          # parameters, BatchNorm statistics, counters
+
+
+def test_second_forward_before_backward_takes_the_eager_path():
+    graphs = make_task(16)
+    model = build(replay=True)
+    np.random.seed(3)
+    c1, d1 = model(graphs[:8])
+    c2, d2 = model(graphs[8:16])            # the capture's activations still belong to the first forward
+    (c1.sum() + d1.mean()).backward()
+    g_first = [p.grad.clone() for p in model.parameters()]
+    model.zero_grad()
+    (c2.sum() + d2.mean()).backward()
+    g_second = [p.grad.clone() for p in model.parameters()]
+    ref = build(replay=False)
+    np.random.seed(3)
+    r1, s1 = ref(graphs[:8])
+    r2, s2 = ref(graphs[8:16])
+    (r1.sum() + s1.mean()).backward()
+    h_first = [p.grad.clone() for p in ref.parameters()]
+    ref.zero_grad()
+    (r2.sum() + s2.mean()).backward()
+    h_second = [p.grad.clone() for p in ref.parameters()]
+    assert torch.equal(c1, r1) and torch.equal(c2, r2)
+    for x, y in zip(g_first + g_second, h_first + h_second):
+        assert torch.equal(x, y)
+
+
+def test_replay_with_dropout_runs_and_draws_fresh_masks():
+    graphs = make_task(8)
+    model = build(dropout=0.5, replay=True)
+    outs = []
+    for _ in range(4):
+        np.random.seed(1)
+        c, d = model(graphs)
+        (c.sum() + d.mean()).backward()
+        outs.append(c.detach().clone())
+        model.zero_grad()
+    assert all(torch.isfinite(o).all() for o in outs)
+    assert any(not torch.equal(outs[0], o) for o in outs[1:])      # BatchNorm statistics are per batch, masks per replay
+
+
+def test_no_grad_and_eval_do_not_use_the_training_capture():
+    graphs = make_task(8)
+    model = build(replay=True)
+    with torch.no_grad():
+        model(graphs)
+    assert not model._train_cache
+    model.eval()
+    model(graphs)
+    assert not model._train_cache and model._eval_cache
