@@ -28,8 +28,6 @@ SIGNATURES = {
     "gnm_agg_num_partials": (_i, [_i, _i, _i]),
     "gnm_sum_partials": (_i, [_p, _i, _p, _p]),
     "gnm_adj_bits_words": (_ll, [_i]),
-    "gnm_aggm_persistent_min_units": (_i, [_i]),
-    "gnm_aggm_persistent_form": (_i, [_i]),
     "gnm_aggm_max_nodes": (_i, []),
     "gnm_aggm_num_partials": (_i, [_i, _i]),
     "gnm_adj_bits_build": (_i, [_p, _p, _p, _p, _p, _i, _p, _p, _p, _p]),

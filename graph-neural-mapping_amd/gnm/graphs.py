@@ -235,7 +235,9 @@ class CapturedTrain:
         m = self.model
         bt = self.static.batch
         X, P0 = bt.arena.features_and_agg0(bt, m._spec.n_avg, not m._spec.learn_eps)
-        return m._run(bt, X, self.perm, want_disc=True, P0=P0, hand_over=False)
+        # (the same score kernel variant as an eager train-mode forward -- the one that also leaves the discriminator's
+        #  backward reductions, unused under torch's own losses -- so that replayed and eager outputs are the same bits)
+        return m._run(bt, X, self.perm, want_disc=True, P0=P0)
 
     def valid_for(self, gh):
         m = self.model
@@ -249,7 +251,18 @@ class CapturedTrain:
         o = self.outstanding
         return o is not None and o() is not None
 
+    def _protect_grads(self):
+        """A .grad that still aliases one of the static gradient buffers (adopted by autograd after the last backward
+        and not cleared since: gradient accumulation) must own its values before a replay overwrites them -- the
+        BACKWARD replay rewrites the buffers, and the FORWARD replay may too (the two graphs share a memory pool, so a
+        gradient buffer can sit where the forward keeps a temporary)."""
+        for p in self._req:
+            g = p.grad
+            if g is not None and g.data_ptr() in self._grad_ptrs:
+                p.grad = g.clone()
+
     def forward(self, gh, perm):
+        self._protect_grads()
         self.static.load_gids(gh)
         if self.static.B > 1:
             self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
@@ -259,12 +272,7 @@ class CapturedTrain:
     def backward(self, dC, dD):
         """replays the backward on the outstanding forward; returns one gradient per parameter (None where unused) as
         FRESH views of the static buffers (a tensor nobody else references is what autograd may adopt as .grad)"""
-        # a .grad that still aliases one of the static buffers (adopted last step and not cleared: gradient
-        # accumulation) must own its values before the replay overwrites them
-        for p in self._req:
-            g = p.grad
-            if g is not None and g.data_ptr() in self._grad_ptrs:
-                p.grad = g.clone()
+        self._protect_grads()
         if dC is None:
             self.dC.zero_()
         else:

@@ -129,16 +129,6 @@ int gnm_sum_partials(const double* partial, int count, float* out, void* stream)
 long long gnm_adj_bits_words(int n);
 int gnm_aggm_max_nodes(void);
 int gnm_aggm_num_partials(int F, int B);
-/* Launches of at least this many units (graphs x 32-column blocks; F >= 32, n_max <= 400) run as ONE persistent
- * workgroup per CU -- 3 loader waves streaming and splitting the next unit's tile into a second LDS plane buffer while
- * 13 compute waves multiply the current one (csrc/aggm.hip, gnm_aggp_kernel) -- instead of a workgroup per unit.  Same
- * results to fp32 rounding, same fixed reduction orders.  v >= 0 sets the threshold (1 = always, a huge value = never),
- * v < 0 only reads it; returns the previous value.  Initial value: environment GNM_AGGP_MIN_UNITS, else never (1 << 30):
- * measured slower than the per-unit kernel at B = 1024 (profiles/r03_aggp_timeline.md). */
-int gnm_aggm_persistent_min_units(int v);
-/* which persistent kernel: 1 = one 13-wave workgroup per CU with two plane buffers, 2 = two 6-wave workgroups per CU with
- * the next tile held in registers; v = 1 / 2 selects, anything else only reads; returns the previous value. */
-int gnm_aggm_persistent_form(int v);
 int gnm_adj_bits_build(const int32_t* rowptr, const uint16_t* col, const int64_t* g_rp_off, const int64_t* g_col_off,
                        const int32_t* g_n, int G, uint32_t* bits, const int64_t* g_bits_off, int32_t* dup,
                        void* stream);

@@ -18,20 +18,6 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-@pytest.fixture(params=["per_unit", "persistent", "persistent2"], autouse=True)
-def aggm_kernel_form(request):
-    """every test of this file runs through both forms of the matrix-core kernel: a workgroup per (graph, column
-    block), and the persistent one-workgroup-per-CU form with loader and compute waves (gnm_aggp_kernel; shapes it does
-    not cover -- n_max > 400, F < 32 -- take the per-unit kernel either way), and the two-workgroups-per-CU persistent
-    form with the next tile held in registers (gnm_aggq_kernel)"""
-    from gnm._cabi import lib
-    old = lib.gnm_aggm_persistent_min_units(1 if request.param != "per_unit" else 1 << 30)
-    old_form = lib.gnm_aggm_persistent_form(2 if request.param == "persistent2" else 1)
-    yield request.param
-    lib.gnm_aggm_persistent_min_units(old)
-    lib.gnm_aggm_persistent_form(old_form)
-
-
 def test_bit_adjacency_matches_the_csr():
     from gnm._cabi import lib
     from gnm.arena import GraphArena
@@ -85,8 +71,7 @@ AGGM_CASES = [
     ([300, 130], 0.15, 128, True),           # four column blocks
     ([45, 45, 45], 0.3, 64, False),          # asymmetric: backward runs on the transposed bit matrix
     ([17] * 11, 0.5, 64, True),              # more graphs than one XCD round
-    ([17] * 300 + [33, 1, 64], 0.5, 64, True),   # 606 units: the persistent form walks 2-3 units per workgroup
-    ([40] * 700, 0.3, 64, True),             # 1,400 units: 5-6 per workgroup, both plane buffers many times over
+    ([17] * 300 + [33, 1, 64], 0.5, 64, True),   # 606 workgroups: several rounds of the chip
     ([400, 400], 0.3, 7, True),              # the input layer: one partial column block, unaligned rows
     ([37, 5, 64, 1, 23], 0.4, 5, True),
     ([45, 45, 45], 0.3, 20, False),
