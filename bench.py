@@ -326,16 +326,15 @@ def main():
         sel = rng.permutation(pool_n)[:B] if pool_n >= B else rng.integers(0, pool_n, B)
         bt = arena.batch_from_gids(gids_all[sel])
         batches.append((bt, labels_all[torch.as_tensor(sel, device=dev)]))
-    N = batches[0][0].N
-    if args.neighbor_pooling == "max":
-        # the neighbour lists the reference's max pooling reads (graphcnn.py:55-81); device arrays per batch, untimed
-        from gnm.maxnb import MaxNeighbours
-        for g in pool:
-            g.build_neighbors()
-        rng2 = np.random.default_rng(1234 + rank)
-        for bt, _ in batches:
-            sel = rng2.permutation(pool_n)[:B] if pool_n >= B else rng2.integers(0, pool_n, B)
+        if args.neighbor_pooling == "max":
+            # the neighbour lists the reference's max pooling reads (graphcnn.py:55-81), built from the SAME selection
+            # as the batch's CSR and features; device arrays per batch, untimed
+            from gnm.maxnb import MaxNeighbours
+            for i in sel:
+                if getattr(pool[i], "neighbors", None) is None:
+                    pool[i].build_neighbors()
             bt.maxnb = MaxNeighbours([pool[i] for i in sel], args.no_learn_eps, dev)
+    N = batches[0][0].N
     d_labels = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev)   # main.py:32, sized by node count
 
     if args.torch_loss:

@@ -26,30 +26,28 @@ typedef unsigned int ev_u32x2 __attribute__((ext_vector_type(2)));
 
 #define GNM_EVAL_MAX_LAYERS 16
 #define GNM_EVAL_MAX_MLP 3
-static constexpr int kEvThreads = 1024;
-static constexpr int kEvWaves = 16;
+static constexpr int kEvThreads = 768;               // 12 waves = 3 per SIMD: 168 registers per lane (the Linear phase
+static constexpr int kEvWaves = 12;                   // holds 48 operand + 32 accumulator registers)
 static constexpr int kEvMaxN = 400;               // 13 row blocks; planes of one 32-column block: 75 KB
 static constexpr int kEvH = 64;
 static constexpr unsigned kEvK8 = 512;            // bytes per k-group (8 rows x 32 columns bf16) of a plane
 static constexpr unsigned kEvStep = 2 * kEvK8;
 
+// Parameter pointers live in a small DEVICE table (the caller fills it once per model; a by-value struct of 400
+// pointers indexed by the layer counter ended up in scratch memory): int64 words,
+//   entry j = l * m + k, 7 words: W, bias, gamma, beta, running_mean, running_var, ldw (Linear k of layer l and the
+//   BatchNorm behind it), then per layer l 2 words: Wp, bp (classifier Linear).
+static constexpr int kEvLinWords = 7;
 struct EvalArgs {
-    // batch
     const uint32_t* adj_bits; const int64_t* b_bits_off; const int32_t* node_off;
     const int32_t* rowptr; const int64_t* b_rp_off;      // degrees (neighbour "average")
     const float* X; int ldx, F0;
     int B, n16_max, L, m, C;
     int average, self_loop, graph_avg;
     float bn_eps;
-    // parameters: [layer][linear]; BatchNorm k of layer l: k < m - 1 the MLP's inner ones, k = m - 1 the layer's outer one
-    const float* W[GNM_EVAL_MAX_LAYERS][GNM_EVAL_MAX_MLP]; int ldw[GNM_EVAL_MAX_LAYERS][GNM_EVAL_MAX_MLP];
-    const float* bias[GNM_EVAL_MAX_LAYERS][GNM_EVAL_MAX_MLP];
-    const float* gamma[GNM_EVAL_MAX_LAYERS][GNM_EVAL_MAX_MLP]; const float* beta[GNM_EVAL_MAX_LAYERS][GNM_EVAL_MAX_MLP];
-    const float* rmean[GNM_EVAL_MAX_LAYERS][GNM_EVAL_MAX_MLP]; const float* rvar[GNM_EVAL_MAX_LAYERS][GNM_EVAL_MAX_MLP];
+    const long long* table;                              // see above
     const float* eps;                                    // [L] or null (learn_eps False)
-    const float* Wp[GNM_EVAL_MAX_LAYERS]; const float* bp[GNM_EVAL_MAX_LAYERS];      // classifier Linears [C, H], [C]
-    // outputs / scratch
-    float* hidden[GNM_EVAL_MAX_LAYERS]; int ldh;         // [N, H] each
+    float* hidden; long long hidden_stride; int ldh;     // [L][N, H]
     float* s0; float* s1; int lds_;                      // two [N, H] scratch arrays (pooled / MLP intermediates)
     float* g_f; int ldgf;                                // [B, L * H]
     float* c_sig;                                        // [B, L * H] sigmoid(g_f), or null
@@ -106,7 +104,10 @@ __global__ void __launch_bounds__(kEvThreads) gnm_eval_encoder_kernel(const Eval
         }
         if (tid < p.C) {
             float acc = 0.f;
-            for (int l = 0; l < p.L; ++l) acc += p.bp[l][tid] + (p.graph_avg ? 0.f / 0.f : 0.f);
+            for (int ll = 0; ll < p.L; ++ll) {
+                const float* bpl = reinterpret_cast<const float*>(p.table[(size_t)p.L * p.m * kEvLinWords + 2 * ll + 1]);
+                acc += bpl[tid] + (p.graph_avg ? 0.f / 0.f : 0.f);
+            }
             p.c_logit[(size_t)b * p.ldc + tid] = acc;
         }
         return;
@@ -125,20 +126,21 @@ __global__ void __launch_bounds__(kEvThreads) gnm_eval_encoder_kernel(const Eval
         v.y = ((tid & 4) ? one : 0u) | ((tid & 8) ? one << 16 : 0u);
         *reinterpret_cast<ev_u32x2*>(lut + 8 * tid) = v;
     }
-    // this wave's rows of the bit adjacency (row block = wave; the same for every layer and column block)
-    unsigned pk[8];
-    {
-        const int rb = min(wave, W - 1);
-        const ev_u32x4* ra = reinterpret_cast<const ev_u32x4*>(gbits + (size_t)(rb * 32 + i) * (2 * HPW) + h * HPW);
+    // a wave's rows of the bit adjacency: row block `wave` is kept in registers for the whole kernel (the same for
+    // every layer and column block); a wave that also owns block wave + 12 loads that one when it gets there
+    auto load_pk = [&](int rb, unsigned (&pkv)[8]) {
+        const ev_u32x4* ra = reinterpret_cast<const ev_u32x4*>(gbits + (size_t)(min(rb, W - 1) * 32 + i) * (2 * HPW) + h * HPW);
         const ev_u32x4 z4 = {0u, 0u, 0u, 0u};
         const ev_u32x4 q0 = ra[0], q1 = HPW > 4 ? ra[1] : z4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pk[j] = q0[j]; pk[4 + j] = q1[j]; }
-    }
+        for (int j = 0; j < 4; ++j) { pkv[j] = q0[j]; pkv[4 + j] = q1[j]; }
+    };
+    unsigned pk0[8];
+    load_pk(wave, pk0);
 
     for (int l = 0; l < p.L; ++l) {
         const int F = l == 0 ? p.F0 : H;
-        const float* xin = l == 0 ? p.X : p.hidden[l - 1];
+        const float* xin = l == 0 ? p.X : p.hidden + (size_t)(l - 1) * p.hidden_stride;
         const int ldin = l == 0 ? p.ldx : p.ldh;
         const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + p.eps[l] : 1.f);
         // ================= 1. aggregation, one 32-column block at a time -> s0 [n, F] =========================
@@ -174,8 +176,14 @@ __global__ void __launch_bounds__(kEvThreads) gnm_eval_encoder_kernel(const Eval
                 }
             }
             __syncthreads();
-            if (wave < W) {
-                const int rb = wave;
+            for (int rb = wave; rb < W; rb += kEvWaves) {
+                unsigned pk[8];
+                if (rb == wave) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pk[j] = pk0[j];
+                } else {
+                    load_pk(rb, pk);
+                }
                 const char* bp0 = planes + h * kEvK8 + i * 16;
                 const char* bp1 = bp0 + plane_bytes;
                 const char* bp2 = bp1 + plane_bytes;
@@ -236,14 +244,20 @@ __global__ void __launch_bounds__(kEvThreads) gnm_eval_encoder_kernel(const Eval
         int K = F;
         for (int k = 0; k < p.m; ++k) {
             const bool last = k == p.m - 1;
-            float* lin_out = last ? p.hidden[l] : ((k & 1) ? p.s0 : p.s1);
+            const long long* te = p.table + (size_t)(l * p.m + k) * kEvLinWords;
+            const float* Wg = reinterpret_cast<const float*>(te[0]);
+            const float* bias_g = reinterpret_cast<const float*>(te[1]);
+            const float* gamma_g = reinterpret_cast<const float*>(te[2]);
+            const float* beta_g = reinterpret_cast<const float*>(te[3]);
+            const float* rmean_g = reinterpret_cast<const float*>(te[4]);
+            const float* rvar_g = reinterpret_cast<const float*>(te[5]);
+            const int ldw = (int)te[6];
+            float* lin_out = last ? p.hidden + (size_t)l * p.hidden_stride : ((k & 1) ? p.s0 : p.s1);
             const int ld_in = (k == 0 || (k & 1) == 0) ? p.lds_ : p.lds_;   // both scratch arrays share a leading dimension
             const int ld_out = last ? p.ldh : p.lds_;
             __syncthreads();           // the previous phase's global writes are visible; weight planes / bnv are free
             // weight planes: entry (mm, c, lane = 32 kg + nn): W[h = 32 c + nn][k = 8 mm + 32 kg + 0..7], zero past K
             {
-                const float* Wg = p.W[l][k];
-                const int ldw = p.ldw[l][k];
                 for (int e = tid; e < E; e += kEvThreads) {
                     const int nn = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % HT, mm = e / (64 * HT);
                     float f[8];
@@ -257,10 +271,10 @@ __global__ void __launch_bounds__(kEvThreads) gnm_eval_encoder_kernel(const Eval
                     Wpl[e] = p1; Wpl[E + e] = p2; Wpl[2 * E + e] = p3;
                 }
                 if (tid < H) {         // bias and the folded eval-mode BatchNorm behind this Linear (running statistics)
-                    const float sc = p.gamma[l][k][tid] * rsqrtf(p.rvar[l][k][tid] + p.bn_eps);
-                    bnv[tid] = p.bias[l][k] ? p.bias[l][k][tid] : 0.f;
+                    const float sc = gamma_g[tid] / sqrtf(rvar_g[tid] + p.bn_eps);
+                    bnv[tid] = bias_g ? bias_g[tid] : 0.f;
                     bnv[H + tid] = sc;
-                    bnv[2 * H + tid] = p.beta[l][k][tid] - p.rmean[l][k][tid] * sc;
+                    bnv[2 * H + tid] = beta_g[tid] - rmean_g[tid] * sc;
                 }
             }
             __syncthreads();
@@ -351,8 +365,9 @@ __global__ void __launch_bounds__(kEvThreads) gnm_eval_encoder_kernel(const Eval
     if (tid < p.C) {
         float acc = 0.f;
         for (int l = 0; l < p.L; ++l) {
-            float z = p.bp[l][tid];
-            const float* w = p.Wp[l] + (size_t)tid * H;
+            const long long* th = p.table + (size_t)p.L * p.m * kEvLinWords + 2 * l;
+            float z = reinterpret_cast<const float*>(th[1])[tid];
+            const float* w = reinterpret_cast<const float*>(th[0]) + (size_t)tid * H;
             for (int c = 0; c < H; ++c) z += gfl[l * H + c] * w[c];
             acc += z;
         }
@@ -362,25 +377,28 @@ __global__ void __launch_bounds__(kEvThreads) gnm_eval_encoder_kernel(const Eval
 
 extern "C" int gnm_eval_max_nodes(void) { return kEvMaxN; }
 
-// One launch = the eval-mode encoder + readout + classifier of B graphs (see the file header).  All pointers are device
-// pointers; the pointer TABLES (W, bias, gamma, beta, rmean, rvar: [L * m] in layer-major order; Wp, bp, hidden: [L]) are
-// host arrays.  H must be 64, 1 <= m <= 3, L <= 16, F0 <= 64, C <= 64, every graph needs a bit adjacency and at most
-// gnm_eval_max_nodes() nodes: GNM_ERR_UNSUPPORTED otherwise (the caller then runs the layer-by-layer path).
-// s0 / s1: two [N, lds] fp32 scratch arrays.  c_sig may be NULL.
+extern "C" long long gnm_eval_table_words(int L, int m) { return (long long)L * m * kEvLinWords + 2LL * L; }
+
+// One launch = the eval-mode encoder + readout + classifier of B graphs (see the file header).  `table`: DEVICE array of
+// gnm_eval_table_words(L, m) int64 words holding the parameter pointers -- entry l * m + k (7 words: W, bias, gamma, beta,
+// running_mean, running_var as device addresses, then the weight's leading dimension) for Linear k of layer l's MLP and
+// the BatchNorm BEHIND it (the MLP's inner BatchNorm k for k < m - 1, the layer's outer BatchNorm for k = m - 1), then
+// per layer 2 words (classifier weight [C, H] row-major, bias [C]).  hidden: [L][N, H] (layer stride hidden_stride
+// floats, leading dimension ldh).  H must be 64, 1 <= m <= 3, L <= 16, F0 <= 64, C <= 64, every graph needs a bit
+// adjacency and at most gnm_eval_max_nodes() nodes: GNM_ERR_UNSUPPORTED otherwise (the caller then runs the
+// layer-by-layer path).  s0 / s1: two [N, lds] fp32 scratch arrays.  c_sig may be NULL.
 extern "C" int gnm_eval_encoder(const uint32_t* adj_bits, const int64_t* b_bits_off, const int32_t* node_off,
                                 const int32_t* rowptr, const int64_t* b_rp_off, int B, int n_max, const float* X, int ldx,
                                 int F0, int H, int L, int m, int C, int average, int self_loop, int graph_avg,
-                                float bn_eps, const float* const* W, const int* ldw, const float* const* bias,
-                                const float* const* gamma, const float* const* beta, const float* const* rmean,
-                                const float* const* rvar, const float* eps, const float* const* Wp,
-                                const float* const* bp, float* const* hidden, int ldh, float* s0, float* s1, int lds_,
-                                float* g_f, int ldgf, float* c_sig, float* c_logit, int ldc, void* stream) {
+                                float bn_eps, const long long* table, const float* eps, float* hidden,
+                                long long hidden_stride, int ldh, float* s0, float* s1, int lds_, float* g_f, int ldgf,
+                                float* c_sig, float* c_logit, int ldc, void* stream) {
     if (B <= 0) return GNM_OK;
     if (H != kEvH || m < 1 || m > GNM_EVAL_MAX_MLP || L < 1 || L > GNM_EVAL_MAX_LAYERS || F0 < 1 || F0 > 64 || C < 1 ||
         C > 64 || n_max < 1 || n_max > kEvMaxN)
         return GNM_ERR_UNSUPPORTED;
-    if (!adj_bits || !b_bits_off || !node_off || !rowptr || !b_rp_off || !X || !W || !ldw || !bias || !gamma || !beta ||
-        !rmean || !rvar || !Wp || !bp || !hidden || !s0 || !s1 || !g_f || !c_logit)
+    if (!adj_bits || !b_bits_off || !node_off || !rowptr || !b_rp_off || !X || !table || !hidden || !s0 || !s1 || !g_f ||
+        !c_logit)
         return GNM_ERR_BAD_ARG;
     if ((reinterpret_cast<uintptr_t>(adj_bits) & 15) || (ldh & 3) || (lds_ & 3)) return GNM_ERR_UNSUPPORTED;
     EvalArgs a;
@@ -388,16 +406,7 @@ extern "C" int gnm_eval_encoder(const uint32_t* adj_bits, const int64_t* b_bits_
     a.adj_bits = adj_bits; a.b_bits_off = b_bits_off; a.node_off = node_off; a.rowptr = rowptr; a.b_rp_off = b_rp_off;
     a.X = X; a.ldx = ldx; a.F0 = F0; a.B = B; a.n16_max = ((n_max + 15) / 16) * 16; a.L = L; a.m = m; a.C = C;
     a.average = average; a.self_loop = self_loop; a.graph_avg = graph_avg; a.bn_eps = bn_eps; a.eps = eps;
-    for (int l = 0; l < L; ++l) {
-        for (int k = 0; k < m; ++k) {
-            const int j = l * m + k;
-            if (!W[j] || !gamma[j] || !beta[j] || !rmean[j] || !rvar[j]) return GNM_ERR_BAD_ARG;
-            a.W[l][k] = W[j]; a.ldw[l][k] = ldw[j]; a.bias[l][k] = bias[j];
-            a.gamma[l][k] = gamma[j]; a.beta[l][k] = beta[j]; a.rmean[l][k] = rmean[j]; a.rvar[l][k] = rvar[j];
-        }
-        if (!Wp[l] || !bp[l] || !hidden[l]) return GNM_ERR_BAD_ARG;
-        a.Wp[l] = Wp[l]; a.bp[l] = bp[l]; a.hidden[l] = hidden[l];
-    }
+    a.table = table; a.hidden = hidden; a.hidden_stride = hidden_stride;
     a.ldh = ldh; a.s0 = s0; a.s1 = s1; a.lds_ = lds_; a.g_f = g_f; a.ldgf = ldgf; a.c_sig = c_sig; a.c_logit = c_logit;
     a.ldc = ldc;
     const size_t lds = (size_t)3 * (a.n16_max / 8) * kEvK8 + (size_t)3 * 4 * 2 * 64 * 16 + 128 + (size_t)3 * kEvH * 4 +

@@ -68,7 +68,8 @@ class Batch:
     """What the kernels need to know about one batch of graphs (all on the device)."""
 
     __slots__ = ("B", "N", "n_max", "n_min", "nnz_max", "arena", "node_off", "rp_off", "col_off", "t_rp_off",
-                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base", "bits_off", "t_bits_off", "dense", "maxnb", "iso")
+                 "t_col_off", "gids", "node_off_host", "symmetric", "feat_base", "bits_off", "t_bits_off", "dense", "maxnb", "iso", "has_bits")
+    # has_bits: every graph of the batch has a bit adjacency (whatever the batch's density): the one-launch eval encoder
     # iso: some graph of the batch has a node without neighbours.  Under neighbour "average" + learn_eps that node's
     # row is 0/0 = NaN (graphcnn.py:157-158) and the reference keeps the NaN to ITS row and its neighbours' -- none -- per
     # layer; the matrix-core product would spread it to every row of the graph (0 x NaN), so such batches take the
@@ -333,6 +334,7 @@ class GraphArena:
             b.t_rp_off, b.t_col_off = tb["trp"][gd], tb["tcol"][gd]
         b.dense = self.dense_ok(gh)
         b.iso = bool(tb["iso_host"][gh].any())
+        b.has_bits = bool(gh.shape[0] > 0 and tb["bits_ok_host"][gh].all())
         b.bits_off = tb["bits"][gd]
         b.t_bits_off = b.bits_off if b.symmetric else tb["tbits"][gd]
         return b
@@ -460,7 +462,7 @@ class StaticBatch:
 
     def __init__(self, template, extra_int64=0):
         b = Batch()
-        for f in ("B", "N", "n_max", "n_min", "nnz_max", "arena", "symmetric", "dense", "iso"):
+        for f in ("B", "N", "n_max", "n_min", "nnz_max", "arena", "symmetric", "dense", "iso", "has_bits"):
             setattr(b, f, getattr(template, f))
         b.node_off_host = np.array(template.node_off_host, copy=True)
         b.node_off = template.node_off.clone()
@@ -508,7 +510,7 @@ class PackedStaticBatch:
     (gnm/graphs.py CapturedEval): assembling a Batch the general way costs ~15 tiny device ops (~150 us of host
     time), which is most of a B = 1 forward."""
 
-    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False, iso=False):
+    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False, iso=False, has_bits=False):
         dev = arena.device
         self.arena, self.B, self.n = arena, int(B), int(n)
         words = 8 * B + (B + 2) // 2                       # 8 int64 vectors + node_off as int32 pairs
@@ -530,6 +532,7 @@ class PackedStaticBatch:
         b.symmetric = bool(symmetric)
         b.dense = bool(dense)
         b.iso = bool(iso)
+        b.has_bits = bool(has_bits)
         b.bits_off = dv[6 * B:7 * B]
         b.t_bits_off = b.bits_off if symmetric else dv[7 * B:8 * B]
         b.rp_off, b.col_off = dv[0:B], dv[B:2 * B]
@@ -548,7 +551,8 @@ class PackedStaticBatch:
         b = self.batch
         return (gh.shape[0] == b.B and bool((tb["n_host"][gh] == self.n).all())
                 and bool(tb["sym_host"][gh].all()) == b.symmetric and int(tb["nnz_host"][gh].max()) <= b.nnz_max
-                and self.arena.dense_ok(gh) == b.dense and bool(tb["iso_host"][gh].any()) == b.iso)
+                and self.arena.dense_ok(gh) == b.dense and bool(tb["iso_host"][gh].any()) == b.iso
+                and bool(tb["bits_ok_host"][gh].all()) == b.has_bits)
 
     def load_gids(self, gh):
         tb = self.arena._tables()

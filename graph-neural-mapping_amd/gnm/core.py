@@ -496,6 +496,92 @@ def _hidden_ptr_arrays(hidden):
 _ptr_array = _hptr_array
 
 
+# GNM_NO_EVAL_FUSED=1: eval-mode forwards through the layer-by-layer kernels only (A/B timing, tests)
+EVAL_FUSED = os.environ.get("GNM_NO_EVAL_FUSED") is None
+
+
+def eval_fused_ok(spec, batch, X, P):
+    """can this eval-mode forward run as the one-launch encoder (csrc/evalfwd.hip)?"""
+    if not EVAL_FUSED or spec.n_max or spec.sync_bn is not None or spec.keep_hidden:
+        return False
+    if not getattr(batch, "has_bits", False) or batch.B < 1 or batch.n_max > int(lib.gnm_eval_max_nodes()):
+        return False
+    if spec.n_avg and spec.learn_eps and getattr(batch, "iso", False):
+        return False            # the 0/0 row of an isolated node must stay confined to its row (see _dense)
+    H = P["batch_norms.0.weight"].shape[0]
+    C_ = P["linears_prediction.0.weight"].shape[0]
+    return H == 64 and 1 <= spec.m <= 3 and spec.L <= 16 and X.shape[1] <= 64 and C_ <= 64 and X.is_cuda
+
+
+def eval_forward_fused(spec, batch, perm, P, X, want_disc):
+    """GIN_InfoMaxReg.forward in eval() mode (graphcnn.py:194-251 with BatchNorm on its running statistics and dropout
+    off) as ONE encoder launch (gnm_eval_encoder: layers + readout + classifier, a workgroup per graph) plus, for the
+    Infomax scores, U = sigmoid(g_f) W^T and the score kernel.  No autograd graph: callers use it under no_grad only
+    (models/graphcnn.py).  Returns (c_logit, d_logit, g_f) like GinInfoMaxFn."""
+    dev = launch_device(X, *[t for t in P.values() if torch.is_tensor(t)][:1])
+    L, m = spec.L, spec.m
+    N, B = batch.N, batch.B
+    H = P["batch_norms.0.weight"].shape[0]
+    Cn = P["linears_prediction.0.weight"].shape[0]
+    f32 = dict(dtype=torch.float32, device=dev)
+    X = X.contiguous()
+    a = batch.arena
+    words = []
+    for l in range(L):
+        for k in range(m):
+            wn = f"mlps.{l}.linear" if m == 1 else f"mlps.{l}.linears.{k}"
+            bn = f"batch_norms.{l}" if k == m - 1 else f"mlps.{l}.batch_norms.{k}"
+            W = P[wn + ".weight"]
+            if W.stride(1) != 1:
+                raise GnmError("Linear weights must be row-contiguous")
+            words += [W.data_ptr(), P[wn + ".bias"].data_ptr(), P[bn + ".weight"].data_ptr(), P[bn + ".bias"].data_ptr(),
+                      P[bn + ".running_mean"].data_ptr(), P[bn + ".running_var"].data_ptr(), W.stride(0)]
+    for l in range(L):
+        wp, bp = P[f"linears_prediction.{l}.weight"], P[f"linears_prediction.{l}.bias"]
+        if not wp.is_contiguous() or not bp.is_contiguous():
+            raise GnmError("classifier parameters must be contiguous")
+        words += [wp.data_ptr(), bp.data_ptr()]
+    assert len(words) == int(lib.gnm_eval_table_words(L, m))
+    # the table of parameter addresses lives on the device; rebuilt only when a parameter moved (a few hundred bytes,
+    # one pinned asynchronous copy -- capturable)
+    key = tuple(words)
+    cached = getattr(spec, "_eval_table", None)
+    if cached is None or cached[0] != key or cached[1].device != dev:
+        host = torch.tensor(words, dtype=torch.int64).pin_memory()
+        cached = spec._eval_table = (key, host.to(dev, non_blocking=True), host)
+    table = cached[1]
+    hidden_all = torch.empty((L, N, H), **f32)
+    hidden = [hidden_all[l] for l in range(L)]
+    s0, s1 = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
+    g_f = torch.empty((B, L * H), **f32)
+    c = torch.empty_like(g_f) if want_disc else None
+    c_logit = torch.empty((B, Cn), **f32)
+    with _stream_scope(dev):
+        check(lib.gnm_eval_encoder(
+            a.bits.buf.data_ptr(), batch.bits_off.data_ptr(), batch.node_off.data_ptr(), a.rowptr.buf.data_ptr(),
+            batch.rp_off.data_ptr(), B, batch.n_max, X.data_ptr(), X.stride(0), X.shape[1], H, L, m, Cn,
+            int(spec.n_avg), int(not spec.learn_eps), int(spec.g_avg), BN_EPS, table.data_ptr(),
+            P["eps"].data_ptr() if spec.learn_eps else None, hidden_all.data_ptr(), hidden_all.stride(0), H,
+            s0.data_ptr(), s1.data_ptr(), H, g_f.data_ptr(), g_f.stride(0), ptr(c), c_logit.data_ptr(),
+            c_logit.stride(0), _stream()), "gnm_eval_encoder")
+        d_logit = torch.zeros((0, 1), **f32)
+        if want_disc:
+            if not batch.equal_n:
+                raise RuntimeError("Discriminator expands each graph summary N//B times (discriminator.py:24): "
+                                   "all graphs of a batch must have the same number of nodes")
+            U = c @ P["disc.f_k.weight"][0].t()                               # U[g] = W c_g
+            if torch.is_tensor(perm) and perm.is_cuda:
+                perm_rows = perm.to(torch.int32)
+            else:
+                perm_rows = torch.as_tensor(perm, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+            d_logit = torch.empty((2 * N, 1), **f32)
+            hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
+            check(lib.gnm_disc_score_fwd(hp_, sp_, tp_, ldh_, L, H, U.data_ptr(), U.stride(0), perm_rows.data_ptr(),
+                                         P["disc.f_k.bias"].data_ptr(), batch.node_off.data_ptr(), N, B,
+                                         d_logit.data_ptr(), _stream()), "gnm_disc_score_fwd")
+    return c_logit, d_logit, g_f
+
+
 class GinInfoMaxFn(torch.autograd.Function):
     """(P0, X, *params) -> (c_logit [B,C], d_logit [2N,1], g_f [B,L*H])."""
 

@@ -84,10 +84,25 @@ class CapturedTrainStep:
         if self._arena_buffers() != self._arena_ptrs:
             raise RuntimeError("the graph arena was re-allocated after this step was captured (graphs were added): "
                                "add every graph before building CapturedTrainStep / FusedTrainStep, or build a new one")
-        self.static.load(batch, extra=labels.to(torch.int64))
+        try:
+            self.static.load(batch, extra=labels.to(torch.int64))
+        except ValueError:
+            # a batch of another class than the captured one (a pool that straddles the density threshold of the
+            # matrix-core aggregation, a graph with an isolated node, another size): the same step, launched eagerly
+            return self._eager(batch, labels, perm)
         self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
         self.graph.replay()
         return self.loss
+
+    def _eager(self, batch, labels, perm):
+        self._zero()
+        X = None if self._agg0_cache else batch.arena.features(batch)
+        c_logit, d_logit = self.model.forward_batch(batch, X=X, perm=perm)
+        loss = self._loss_fn(c_logit, d_logit, labels)
+        loss.backward()
+        if self._post is not None:
+            self._post()
+        return loss
 
 
 class CapturedEval:
@@ -110,7 +125,8 @@ class CapturedEval:
         nnz_cap = max(4096, 1 << (nnz - 1).bit_length()) if nnz > 0 else 4096     # launch parameters sized for this
         self.model = model
         self.static = PackedStaticBatch(arena, gh.shape[0], n, bool(tb["sym_host"][gh].all()), nnz_cap,
-                                        dense=arena.dense_ok(gh), iso=bool(tb["iso_host"][gh].any()))
+                                        dense=arena.dense_ok(gh), iso=bool(tb["iso_host"][gh].any()),
+                                        has_bits=bool(tb["bits_ok_host"][gh].all()))
         self.static.load_gids(gh)
         dev = arena.device
         B = gh.shape[0]
@@ -186,7 +202,8 @@ class CapturedTrain:
         nnz_cap = max(4096, 1 << (nnz - 1).bit_length()) if nnz > 0 else 4096
         self.model = model
         self.static = PackedStaticBatch(arena, gh.shape[0], n, bool(tb["sym_host"][gh].all()), nnz_cap,
-                                        dense=arena.dense_ok(gh), iso=bool(tb["iso_host"][gh].any()))
+                                        dense=arena.dense_ok(gh), iso=bool(tb["iso_host"][gh].any()),
+                                        has_bits=bool(tb["bits_ok_host"][gh].all()))
         self.static.load_gids(gh)
         dev = arena.device
         B = gh.shape[0]

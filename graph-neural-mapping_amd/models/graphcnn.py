@@ -32,7 +32,8 @@ for _p in (_PKG, _HERE):
 from mlp import MLP  # noqa: E402
 from discriminator import Discriminator  # noqa: E402
 from gnm.arena import GraphArena  # noqa: E402
-from gnm.core import DISC_UNIT, DiscUnit, GinInfoMaxFn, GinSpec  # noqa: E402
+from gnm.core import (DISC_UNIT, DiscUnit, GinInfoMaxFn, GinSpec, eval_forward_fused,  # noqa: E402
+                      eval_fused_ok)
 
 __all__ = ["GIN_InfoMaxReg", "GraphCNN", "MLP", "Discriminator"]
 
@@ -123,6 +124,9 @@ class GIN_InfoMaxReg(nn.Module):
         # train_replay = False turns it off
         self.train_replay = True
         self._train_cache = {}
+        # eval-mode forwards under torch.no_grad() (incl. the replayed ones) run the L layers as ONE encoder launch
+        # (csrc/evalfwd.hip) when the shape allows; eval_fused = False keeps the layer-by-layer kernels
+        self.eval_fused = True
 
     @staticmethod
     def _check_kernel_limits(num_layers, input_dim, hidden_dim):
@@ -166,6 +170,13 @@ class GIN_InfoMaxReg(nn.Module):
 
     def _run(self, batch, X, perm, want_disc, P0=None, hand_over=True):
         names, tensors, buffers = self._param_lists()
+        if not self.training and self.eval_fused and not torch.is_grad_enabled() and not X.requires_grad:
+            # evaluation without autograd (the replayed eval forward; callers under torch.no_grad()): one encoder launch
+            # for all layers instead of ~20 launches per layer (csrc/evalfwd.hip)
+            P = dict(zip(names, tensors))
+            P.update(buffers)
+            if eval_fused_ok(self._spec, batch, X, P):
+                return eval_forward_fused(self._spec, batch, perm, P, X, want_disc)
         hold = None
         if want_disc and self.training and DISC_UNIT and hand_over and torch.is_grad_enabled():
             # let the score kernel leave the backward's reductions for the reference's BCE loss (gnm/core.py DiscUnit);

@@ -229,6 +229,28 @@ int gnm_bn_bwd_apply(const float* G, int ldg, const float* Z, int ldz, const flo
                      const float* cA, const float* m1, const float* m2, float* dZ, int ldd, long long N, int H,
                      void* stream);
 
+/* ---- one-launch evaluation encoder (graphcnn.py:208-231 in eval() mode; main.py:49-57, 71-82) ----------
+ * The L GIN layers (aggregation -> MLP -> BatchNorm on its RUNNING statistics -> ReLU), the per-layer graph readout and
+ * the classifier head of B graphs in ONE launch, one workgroup per graph (csrc/evalfwd.hip): what the reference's
+ * per-graph evaluation loop calls once per graph.
+ * table: DEVICE array of gnm_eval_table_words(L, m) int64 words with the parameter addresses -- entry l * m + k (7 words:
+ * W, bias, gamma, beta, running_mean, running_var, then the weight's leading dimension) for Linear k of layer l's MLP
+ * and the BatchNorm BEHIND it (the MLP's inner BatchNorm k for k < m - 1, the layer's outer BatchNorm for k = m - 1),
+ * followed by 2 words per layer (classifier weight [C, H] row-major, classifier bias [C]).
+ * eps: [L] or NULL (learn_eps False: self loops).  hidden: OUTPUT, the L hidden layers [L][N, H] (layer stride
+ * hidden_stride floats, leading dimension ldh); s0 / s1: two [N, lds] fp32 scratch arrays.  Outputs: hidden, g_f
+ * [B, L * H], c_sig = sigmoid(g_f) (may be NULL), c_logit [B, C].
+ * GNM_ERR_UNSUPPORTED (nothing launched; run the layer-by-layer entry points): H != 64, m > 3, L > 16, F0 > 64, C > 64,
+ * a graph of more than gnm_eval_max_nodes() nodes (every graph needs a bit adjacency).  Arithmetic: the training kernels'
+ * (three-plane bf16 splits, fp32 accumulation); results agree with them to fp32 rounding. */
+int gnm_eval_max_nodes(void);
+long long gnm_eval_table_words(int L, int m);
+int gnm_eval_encoder(const uint32_t* adj_bits, const int64_t* b_bits_off, const int32_t* node_off, const int32_t* rowptr,
+                     const int64_t* b_rp_off, int B, int n_max, const float* X, int ldx, int F0, int H, int L, int m, int C,
+                     int average, int self_loop, int graph_avg, float bn_eps, const long long* table, const float* eps,
+                     float* hidden, long long hidden_stride, int ldh, float* s0, float* s1, int lds, float* g_f, int ldgf,
+                     float* c_sig, float* c_logit, int ldc, void* stream);
+
 /* ---- Infomax discriminator (discriminator.py:19-38, graphcnn.py:233-246) ------------
  * hptrs_host: HOST array of L device pointers to the per-layer [N,H] hidden states
  * (n_f is never concatenated).  A layer may instead be given as the pre-BatchNorm output Z_l of its last Linear
