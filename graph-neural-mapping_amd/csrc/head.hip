@@ -160,3 +160,4 @@ extern "C" int gnm_head_bwd(const float* dC, int lddc, const float* masks, const
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
+

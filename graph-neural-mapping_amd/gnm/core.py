@@ -740,6 +740,8 @@ class GinInfoMaxFn(torch.autograd.Function):
             if hold is not None:
                 hold.k = hold.dD_ptr = None
             Wd = P["disc.f_k.weight"][0]
+            # (the three [B, L*H]-sized products of the tail stay library GEMMs: a hand-written fp32-MFMA kernel was
+            #  tried in round 3 and measured 48 us per product against 9-12 us -- 25-80 workgroups do not fill the chip)
             if sink is not None:
                 torch.mm(dU.t(), c, out=sink["disc.f_k.weight"][0])
                 torch.sum(dsum, 0, keepdim=True, out=sink["disc.f_k.bias"])

@@ -124,6 +124,7 @@ class CapturedEval:
         nnz = int(tb["nnz_host"][gh].max())
         nnz_cap = max(4096, 1 << (nnz - 1).bit_length()) if nnz > 0 else 4096     # launch parameters sized for this
         self.model = model
+        self._fused = getattr(model, "eval_fused", False)
         self.static = PackedStaticBatch(arena, gh.shape[0], n, bool(tb["sym_host"][gh].all()), nnz_cap,
                                         dense=arena.dense_ok(gh), iso=bool(tb["iso_host"][gh].any()),
                                         has_bits=bool(tb["bits_ok_host"][gh].all()))
@@ -159,9 +160,11 @@ class CapturedEval:
             return m._run(bt, X, self.perm, want_disc=True, P0=P0)
 
     def valid_for(self, gh):
-        """still replayable for these graphs?  (shape fits, and neither the arena nor the parameters moved)"""
+        """still replayable for these graphs?  (shape fits, and neither the arena nor the parameters moved, nor the
+        choice between the layer-by-layer kernels and the one-launch encoder)"""
         return (self.static.fits(gh) and self._arena_buffers() == self._arena_ptrs
-                and tuple(t.data_ptr() for t in self._params) == self._param_ptrs)
+                and tuple(t.data_ptr() for t in self._params) == self._param_ptrs
+                and getattr(self.model, "eval_fused", False) == self._fused)
 
     def run(self, gh, perm):
         """replay on the graphs with arena ids gh (host int64 [B]) and the permutation of graphcnn.py:199;
@@ -218,11 +221,28 @@ class CapturedTrain:
         self.outstanding = None        # weak reference to the outputs of a replayed forward that has not been backpropagated
         keep = [b for b in model.buffers()]                # BatchNorm statistics: the warm-up passes must not count
         snapshot = [t.clone() for t in keep]
-        sink, model._spec.grad_sink = model._spec.grad_sink, None     # plain autograd gradients inside the capture
+        # The gradients land in ONE persistent buffer of this object (ordinary allocation, outside the graphs' memory
+        # pool, so no replay's temporaries can sit on it): the backward kernels write them there directly
+        # (GinSpec.grad_sink) and autograd is handed views of it.
+        names = [nm for nm, _ in model.named_parameters()]
+        self._flat = torch.zeros(sum(p.numel() for p in self._params), dtype=torch.float32, device=dev)
+        own_sink, off = {}, 0
+        for nm, p in zip(names, self._params):
+            own_sink[nm] = self._flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        sink = model._spec.grad_sink
         try:
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(s):
+                # which parameters get a gradient at all (eps does not when learn_eps is False): one plain pass
+                model._spec.grad_sink = None
+                c, d, _ = self._forward()
+                plain = torch.autograd.grad((c, d), self._req, (torch.zeros_like(c), torch.zeros_like(d)), allow_unused=True)
+                used = iter([g is not None for g in plain])
+                self._has_grad = [bool(next(used)) if p.requires_grad else False for p in self._params]
+                del plain
+                model._spec.grad_sink = own_sink
                 for _ in range(warmup):
                     c, d, _ = self._forward()
                     torch.autograd.grad((c, d), self._req, (torch.zeros_like(c), torch.zeros_like(d)), allow_unused=True)
@@ -235,16 +255,26 @@ class CapturedTrain:
             self.dD = torch.zeros_like(self.d_logit)
             self.bwd_graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), capture_error_mode="thread_local"):
-                self.grads = torch.autograd.grad((self.c_logit, self.d_logit), self._req, (self.dC, self.dD),
-                                                 allow_unused=True)
+                torch.autograd.grad((self.c_logit, self.d_logit), self._req, (self.dC, self.dD), allow_unused=True)
         finally:
             model._spec.grad_sink = sink
-        with torch.no_grad():
-            for t, s0 in zip(keep, snapshot):
-                t.copy_(s0)
+            # the warm-up (and captured) passes ran real forwards: BatchNorm statistics and counters go back to what
+            # they were -- also when the capture failed and the caller falls back to the eager path
+            with torch.no_grad():
+                for t, s0 in zip(keep, snapshot):
+                    t.copy_(s0)
+        self.grads = [own_sink[nm] if has else None for nm, has in zip(names, self._has_grad)]
         torch.cuda.synchronize(dev)
         self._arena_ptrs = self._arena_buffers()
+        # The captured kernels read the graph pool at the addresses of capture time.  A forward re-checks them
+        # (valid_for), but the arena may GROW between a replayed forward and its backward (another batch's graphs added
+        # in between: the arena then moves to bigger buffers and drops the old ones) -- so this capture keeps the
+        # buffers it was recorded on alive: they stay complete for the graphs it can be replayed on.
+        a = arena
+        self._arena_refs = (a.rowptr.buf, a.col.buf, a.feat.buf, a.bits.buf,
+                            tuple(v["buf"] for v in a._agg0.values() if v["buf"] is not None))
         self._grad_ptrs = frozenset(g.data_ptr() for g in self.grads if g is not None)
+        self._flat.zero_()
 
     _arena_buffers = CapturedEval._arena_buffers
 
@@ -269,17 +299,17 @@ class CapturedTrain:
         return o is not None and o() is not None
 
     def _protect_grads(self):
-        """A .grad that still aliases one of the static gradient buffers (adopted by autograd after the last backward
-        and not cleared since: gradient accumulation) must own its values before a replay overwrites them -- the
-        BACKWARD replay rewrites the buffers, and the FORWARD replay may too (the two graphs share a memory pool, so a
-        gradient buffer can sit where the forward keeps a temporary)."""
+        """A .grad that still aliases the gradient buffer (adopted by autograd after the last backward and not cleared
+        since: gradient accumulation) must own its values before the backward replay rewrites the buffer.  (The forward
+        replay cannot touch it: the buffer lives outside the graphs' memory pool -- in a first version the gradients
+        were outputs of the backward graph inside the shared pool, where the next forward replay's temporaries
+        overwrote them.)"""
         for p in self._req:
             g = p.grad
             if g is not None and g.data_ptr() in self._grad_ptrs:
                 p.grad = g.clone()
 
     def forward(self, gh, perm):
-        self._protect_grads()
         self.static.load_gids(gh)
         if self.static.B > 1:
             self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
@@ -300,9 +330,4 @@ class CapturedTrain:
             self.dD.copy_(dD)
         self.bwd_graph.replay()
         self.outstanding = None
-        it = iter(self.grads)
-        out = []
-        for p in self._params:
-            g = next(it) if p.requires_grad else None
-            out.append(g.view_as(g) if g is not None else None)
-        return out
+        return [g.view_as(g) if g is not None else None for g in self.grads]

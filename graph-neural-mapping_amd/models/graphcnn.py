@@ -124,9 +124,12 @@ class GIN_InfoMaxReg(nn.Module):
         # train_replay = False turns it off
         self.train_replay = True
         self._train_cache = {}
-        # eval-mode forwards under torch.no_grad() (incl. the replayed ones) run the L layers as ONE encoder launch
-        # (csrc/evalfwd.hip) when the shape allows; eval_fused = False keeps the layer-by-layer kernels
-        self.eval_fused = True
+        # eval_fused = True: eval-mode forwards under torch.no_grad() (incl. the replayed ones) run the L layers as ONE
+        # encoder launch, a workgroup per graph (csrc/evalfwd.hip), when the shape allows.  Off by default: measured
+        # at one 400-node graph per forward it is SLOWER than the replayed layer-by-layer kernels (0.245 vs 0.188 ms per
+        # graph, gpurun_out/r03i_time_eval.log) -- one CU runs a graph's whole chain (MFMA floor ~57 us + 50 barriers)
+        # where the ~110 replayed launches (~1.4 us apiece) each spread over several CUs.  DESIGN.md section 6.
+        self.eval_fused = False
 
     @staticmethod
     def _check_kernel_limits(num_layers, input_dim, hidden_dim):

@@ -30,6 +30,7 @@ def random_model(L, m, f0, C, learn_eps, gpool, npool, seed):
                 prm.copy_(torch.rand(prm.shape, generator=g) + 0.5 if name.endswith("weight")
                           else torch.randn(prm.shape, generator=g) * 0.2)
         model.eps.copy_(torch.randn(L, generator=g) * 0.3)
+    model.eval_fused = True                # (off by default: see models/graphcnn.py)
     return model.eval()
 
 
@@ -64,6 +65,7 @@ def test_fused_eval_equals_the_layer_by_layer_path(L, m, f0, C, learn_eps, gpool
     outs = []
     for fused in (True, False):
         model.eval_fused = fused
+        model._eval_cache = {}
         with torch.no_grad():
             np.random.seed(4)
             c_logit, d_logit = model(graphs)
@@ -96,6 +98,7 @@ def test_fused_eval_vs_fp64_oracle_and_golden():
     case = "true_s0_eps1_gsum_nsum"
     cfg, state, d = load_case(case)
     model = make_model(cfg, state).eval()
+    model.eval_fused = True
     graphs = make_graphs(cfg, d)
     with torch.no_grad():
         np.random.seed(cfg["np_seed"])
@@ -114,6 +117,7 @@ def test_fused_eval_vs_fp64_oracle_and_golden():
 def test_fused_eval_other_true_shape_goldens(case):
     cfg, state, d = load_case(case)
     model = make_model(cfg, state).eval()
+    model.eval_fused = True
     graphs = make_graphs(cfg, d)
     with torch.no_grad():
         np.random.seed(cfg["np_seed"])
@@ -149,6 +153,7 @@ def test_shapes_outside_the_encoder_fall_back(monkeypatch):
     torch.manual_seed(0)
     m32 = GIN_InfoMaxReg(2, 2, 5, 32, 2, 0.5, True, "sum", "sum", dev).to(dev).eval()
     m64 = GIN_InfoMaxReg(2, 2, 5, 64, 2, 0.5, True, "sum", "sum", dev).to(dev).eval()
+    m32.eval_fused = m64.eval_fused = True
     with torch.no_grad():
         m32(random_graphs(rng, [40, 40], 0.3, True, f0=5))
         m64(random_graphs(rng, [401, 401], 0.1, True, f0=5))

@@ -1012,3 +1012,4 @@ def test_aggregation_of_graphs_too_large_for_lds(average, learn_eps, F):
         assert cnt == lib.gnm_agg_num_partials(F, batch.n_max, batch.B) > 0
         want = float((dp64 * x64).sum())
         assert abs(float(part[:cnt].sum().item()) - want) <= 1e-6 * float(np.abs(dp64 * x64).sum())
+

@@ -82,6 +82,7 @@ def capture_layers(model):
     from gnm import core
     model.eval_replay = False       # the hook below copies to the host inside the forward: not capturable
     model.eval_fused = False        # ... and it hooks the layer-by-layer encoder (the one-launch one: test_gpu_eval_fused.py)
+    model.train_replay = False
     store = {}
     orig = core.encoder_forward
 

@@ -85,8 +85,11 @@ def test_second_forward_before_backward_takes_the_eager_path():
     (r2.sum() + s2.mean()).backward()
     h_second = [p.grad.clone() for p in ref.parameters()]
     assert torch.equal(c1, r1) and torch.equal(c2, r2)
-    for x, y in zip(g_first + g_second, h_first + h_second):
-        assert torch.equal(x, y)
+    assert torch.equal(d1, s1) and torch.equal(d2, s2)
+    names = [k for k, _ in model.named_parameters()]
+    bad = [("first " if j < len(names) else "second ") + names[j % len(names)]
+           for j, (x, y) in enumerate(zip(g_first + g_second, h_first + h_second)) if not torch.equal(x, y)]
+    assert not bad, bad
 
 
 def test_replay_with_dropout_runs_and_draws_fresh_masks():

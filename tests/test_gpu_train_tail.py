@@ -275,7 +275,8 @@ def test_fused_loss_takes_the_discriminator_hand_over(case, scale, monkeypatch):
 
     def run(mode):
         model = make_model(cfg, state).train()
-        np.random.seed(3)
+        model.train_replay = False          # the hand-over lives on the eager path (a replayed backward is captured once,
+        np.random.seed(3)                   # before any loss exists, with the general pass in it)
         c_logit, d_logit = model(graphs)
         if mode == "torch":
             N = d_logit.shape[0] // 2
@@ -313,6 +314,7 @@ def test_discriminator_hand_over_is_not_used_when_the_gradient_was_summed():
     res = []
     for hand_over in (True, False):
         model = make_model(cfg, state).train()
+        model.train_replay = False
         np.random.seed(3)
         c_logit, d_logit = model(graphs)
         if not hand_over:
