@@ -68,6 +68,19 @@ __global__ void __launch_bounds__(UNIT ? 256 : 1024) gnm_disc_score_kernel(const
     const int nthreads = blockDim.x, nwaves = nthreads >> 6;      // 256 threads, or 1024 for batches of few graphs
     unsigned tmask = 0;                                // layers given as Z (workgroup-uniform)
     for (int l = 0; l < L; ++l) tmask |= hp.sc[l] ? 1u << l : 0u;
+    // The first row group of every wave is requested BEFORE the workgroup's prologue (U / BatchNorm vectors into LDS,
+    // the shuffled-branch score by wave 0: a dependent chain of a few microseconds in a workgroup that lives ~20):
+    // those loads depend on nothing the prologue produces (round 3).
+    constexpr int MLE = 5;
+    float4 xe[MLE];
+    if constexpr (LPR4 > 0) {
+        if (n > 0) {
+            const int sub_e = lane & (LPR4 - 1), slot_e = lane / LPR4;
+            const size_t vo = (size_t)(row0 + min(wave * (64 / LPR4) + slot_e, n - 1)) * ldh + 4 * sub_e;
+#pragma unroll
+            for (int l = 0; l < MLE; ++l) xe[l] = *reinterpret_cast<const float4*>(hp.p[min(l, L - 1)] + vo);
+        }
+    }
     for (int e = tid; e < L * H; e += nthreads) {
         Us[e] = U[(size_t)g * ldu + e];
         const int l = e / H, c = e - l * H;
@@ -164,7 +177,9 @@ __global__ void __launch_bounds__(UNIT ? 256 : 1024) gnm_disc_score_kernel(const
 #pragma unroll
         for (int l = 0; l < ML; ++l) du[l] = make_float4(0.f, 0.f, 0.f, 0.f);
         int r = wave * G + slot;
-        GNM_DS_LOAD(xa, r)
+        static_assert(ML == MLE, "the early request covers the same layers");
+#pragma unroll
+        for (int l = 0; l < ML; ++l) xa[l] = xe[l];             // (requested at kernel entry)
         for (; r - slot < n; r += 2 * stride) {         // wave-uniform trip count (r - slot is the wave's first row)
             GNM_DS_LOAD(xb, r + stride)
             GNM_DS_FINISH(xa, r)

@@ -652,6 +652,8 @@ class GinInfoMaxFn(torch.autograd.Function):
             d_logit = torch.empty((2 * N, 1), dtype=torch.float32, device=X.device)
             hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
             rc = -2
+            tm_ = _timed("disc_score", N=N, L=L, H=H)
+            tm_.__enter__()
             if isinstance(want_disc, DiscUnit) and training:
                 # also leave the backward's per-graph reductions (up to the loss's scalar factor): see DiscUnit
                 ldunit = (L * H + 2 + 3) & ~3
@@ -671,6 +673,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                                              perm_rows.data_ptr(), P["disc.f_k.bias"].data_ptr(),
                                              batch.node_off.data_ptr(), N, B, d_logit.data_ptr(), _stream()),
                       "gnm_disc_score_fwd")
+            tm_.__exit__(None, None, None)
         ctx.spec, ctx.batch, ctx.names, ctx.P = spec, batch, names, P
         ctx.hidden, ctx.saved, ctx.g_f, ctx.masks, ctx.Wp = hidden, saved, g_f, masks, Wp
         ctx.fused_head, ctx.wps = fused_head, wps
