@@ -928,6 +928,169 @@ static int launch_lin_split(const LinArgs& a0, int grid, hipStream_t s) {
     return GNM_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// Split-precision Linear for K = 128, H = 128 (round 3: every hidden Linear of BASELINE configs[3], forward and dgrad).
+// The fp32-instruction kernels run this shape at 121 us per [256,000 x 128 x 128] launch = 69 TFLOP/s, 44 % of the
+// fp32 matrix peak, while moving 2.1 TB/s: matrix-pipe bound.  The K = 64 kernel above does not stretch -- three weight
+// planes of [128 x 128] are 98 KB and its per-wave fp32 staging image would be 17 KB: room for 3 waves -- so this one
+// keeps ONLY the weight planes in LDS and loads the A fragments in operand order straight from global memory: lane
+// (i, h) reads row i's 32 bytes at k = 64 kk + 8 m + 32 h (two 16-byte loads per m; a row's 512 bytes are touched by
+// 16 instructions of the same wave, served by L1 / L2 after the first), splits them in registers (optionally after the
+// BatchNorm + ReLU prologue, whose vectors sit in LDS) and issues the six bf16 terms per 16 k against the planes.
+// Twelve waves per CU (one workgroup; 168 registers), tiles of 32 rows dealt to the waves as in the K = 64 kernel, so
+// the launch writes the same gnm_linear_grid(N) rows of statistics partials.  The accumulators are stored as they stand
+// (lane = column: 128-byte row segments, 4 bytes per lane).
+// ---------------------------------------------------------------------------------
+static constexpr int kSplit128Waves = 12;
+
+__global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(const LinArgs p) {
+    constexpr int K = 128, HT = 4, HP = 128, NW = kSplit128Waves, NT = NW * 64;
+    constexpr int E = 2 * 4 * HT * 64;              // 16-byte operand entries per weight plane: [kk][m][c][lane]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* Wp = reinterpret_cast<u32x4*>(smem);                              // [3][E]
+    float* psv = reinterpret_cast<float*>(smem + (size_t)3 * E * 16);        // [3][K]: prologue scale / shift, bias
+    // column statistics of this wave, fp64, in LDS ([2][HP] per wave: 16 registers a lane could not spare -- with them
+    // in registers the tile loop spilled 21)
+    double* wst = reinterpret_cast<double*>(smem + (size_t)3 * E * 16 + 3 * K * 4) + (size_t)(threadIdx.x >> 6) * 2 * HP;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31;
+    const int h = lane >> 5;
+    const bool pro = p.pro_scale != nullptr;
+    // weight planes: entry (kk, m, c, lane = 32 kg + n) = W[h = 32 c + n][k = 64 kk + 8 m + 32 kg + 0..7]
+    for (int e = tid; e < E; e += NT) {
+        const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) & 3, m = (e >> 8) & 3, kk = e >> 10;
+        const int k0 = 64 * kk + 8 * m + 32 * kg, hh = 32 * c + n;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            f[j] = p.w_kmajor ? p.W[(size_t)(k0 + j) * p.ldw + hh] : p.W[(size_t)hh * p.ldw + k0 + j];
+        u32x4 p1, p2, p3;
+        lin_split8(f, p1, p2, p3);
+        Wp[e] = p1; Wp[E + e] = p2; Wp[2 * E + e] = p3;
+    }
+    for (int e = tid; e < K; e += NT) {
+        psv[e] = pro ? p.pro_scale[e] : 1.f;
+        psv[K + e] = pro ? p.pro_shift[e] : 0.f;
+        psv[2 * K + e] = p.bias ? p.bias[e] : 0.f;           // (H == K == 128)
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): nothing from the preamble is pending inside the tile loop
+    __syncthreads();
+
+    const int gw = blockIdx.x * NW + wave;
+    const int ntiles = (gw < 4 * p.stat_rows) ? (p.N + 31) / 32 : 0;
+    const int tstride = 4 * p.stat_rows;
+    const int in_voff = (i * p.ldx + 32 * h) * 4;
+    for (int e = lane; e < 2 * HP; e += 64) wst[e] = 0.0;       // (wave-private: no barrier needed)
+
+    for (int t = gw; t < ntiles; t += tstride) {
+        const int r0 = t * 32;
+        const int rows = min(p.N - r0, 32);
+        const __amdgpu_buffer_rsrc_t rs = gnm_tile_rsrc(p.X + (size_t)r0 * p.ldx, rows, p.ldx, K);
+        f32x16 acc[HT];
+#pragma unroll
+        for (int c = 0; c < HT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+        // eight k steps of 16 (k = 64 kk + 8 m + 32 h + 0..7, step = 4 kk + m) as a REAL loop with the next step's two
+        // 16-byte loads requested before the current step's split and MFMAs (fully unrolled, the scheduler hoisted every
+        // load and split of the 192-MFMA body: 295 spilled registers; with all of a k half in flight still 40)
+        u32x4 cur0 = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, 0, 0);
+        u32x4 cur1 = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, 16, 0);
+#pragma nounroll
+        for (int step = 0; step < 8; ++step) {
+            const int nstep = min(step + 1, 7);
+            const int nko = (64 * (nstep >> 2) + 8 * (nstep & 3)) * 4;
+            const u32x4 nxt0 = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, nko, 0);
+            const u32x4 nxt1 = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, nko + 16, 0);
+            const float4 v0 = __builtin_bit_cast(float4, cur0), v1 = __builtin_bit_cast(float4, cur1);
+            float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (pro) {
+                // (a clipped row read zeros and the affine map moves them: its products land in accumulator rows that
+                //  are neither stored nor counted)
+                const int k0 = 64 * (step >> 2) + 8 * (step & 3) + 32 * h;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 sc = *reinterpret_cast<const float4*>(psv + k0 + 4 * q);
+                    const float4 sh = *reinterpret_cast<const float4*>(psv + K + k0 + 4 * q);
+                    f[4 * q + 0] = f[4 * q + 0] * sc.x + sh.x; f[4 * q + 1] = f[4 * q + 1] * sc.y + sh.y;
+                    f[4 * q + 2] = f[4 * q + 2] * sc.z + sh.z; f[4 * q + 3] = f[4 * q + 3] * sc.w + sh.w;
+                }
+                if (p.pro_relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = gnm_relu(f[j]);
+                }
+            }
+            u32x4 A1, A2, A3;
+            lin_split8(f, A1, A2, A3);
+            const lin_bf16x8 a1 = __builtin_bit_cast(lin_bf16x8, A1), a2 = __builtin_bit_cast(lin_bf16x8, A2),
+                             a3 = __builtin_bit_cast(lin_bf16x8, A3);
+#pragma unroll
+            for (int c = 0; c < HT; ++c) {
+                const int e = ((step * HT + c) << 6) + lane;
+                const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wp[e]), b2 = __builtin_bit_cast(lin_bf16x8, Wp[E + e]),
+                                 b3 = __builtin_bit_cast(lin_bf16x8, Wp[2 * E + e]);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[c], 0, 0, 0);      // small terms first
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[c], 0, 0, 0);
+                acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[c], 0, 0, 0);
+            }
+            cur0 = nxt0; cur1 = nxt1;
+        }
+        // ---- epilogue: bias, column statistics, stores (lane = column; rows past N clipped by the descriptor) ----
+        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, rows, p.ldz, HP);
+#pragma unroll
+        for (int c = 0; c < HT; ++c) {
+            float s1 = 0.f, s2 = 0.f;
+            const float bz = psv[2 * K + 32 * c + i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float z = acc[c][r] + bz;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), rz, (unsigned)((lrow * p.ldz + 32 * c + i) * 4), 0, 0);
+                if (lrow < rows) {
+                    s1 += z;
+                    s2 += z * z;
+                }
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                wst[32 * c + i] += (double)s1;
+                wst[HP + 32 * c + i] += (double)s2;
+            }
+        }
+    }
+
+    if (p.stats_partial) {
+        const double* red = reinterpret_cast<const double*>(smem + (size_t)3 * E * 16 + 3 * K * 4);   // [NW waves][2][HP]
+        __syncthreads();
+        for (int idx = tid; idx < 3 * 2 * HP; idx += NT) {        // three rows of partials per workgroup, as above
+            const int grp = idx / (2 * HP), rest = idx - grp * 2 * HP;
+            const int which = rest / HP, col = rest - which * HP;
+            const int row = blockIdx.x * 3 + grp;
+            if (row >= p.stat_rows) continue;
+            double sacc = 0.0;
+            for (int w = 4 * grp; w < 4 * grp + 4; ++w) sacc += red[(w * 2 + which) * HP + col];
+            p.stats_partial[((size_t)row * 2 + which) * p.H + col] = sacc;
+        }
+    }
+}
+
+static int launch_lin_split128(const LinArgs& a0, int grid, hipStream_t s) {
+    LinArgs a = a0;
+    a.stat_rows = grid;
+    const int grid3 = (grid + 2) / 3;
+    const size_t lds = (size_t)3 * (2 * 4 * 4 * 64) * 16 + (size_t)3 * 128 * 4 + (size_t)kSplit128Waves * 2 * 128 * 8;
+    GNM_ALLOW_FULL_LDS((&gnm_lin_split128_kernel));
+    hipLaunchKernelGGL(gnm_lin_split128_kernel, dim3(grid3), dim3(kSplit128Waves * 64), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 static bool lin_no_split() {
 #ifdef GNM_LIN_FORCE_NO_SPLIT          // variant builds for paired timing (tools/build_variant.py)
     return true;
@@ -1019,6 +1182,8 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
             rc = launch_lin_split<2>(a, grid, s);
             if (rc != GNM_ERR_UNSUPPORTED) return rc;
         }
+        // K = H = 128 (configs[3]): its own split-precision kernel
+        if (K == 128 && H == 128 && small_ld && !lin_no_split()) return launch_lin_split128(a, grid, s);
         if ((K == 32 || K == 64) && small_ld && !lin_no_stream()) {
 #define GNM_LINS_CASE(KC_, HT_) if (K == KC_ && HT == HT_) rc = launch_lin_stream<KC_, HT_>(a, grid, s);
             GNM_LINS_CASE(32, 1) GNM_LINS_CASE(32, 2) GNM_LINS_CASE(32, 3) GNM_LINS_CASE(32, 4)

@@ -221,7 +221,7 @@ def test_agg_backward_fused_with_bn_stats(sizes, density, average, learn_eps, gr
 
 
 LIN_CASES = [(1000, 64, 64), (1000, 7, 64), (33, 64, 64), (1, 5, 32), (777, 128, 128), (500, 32, 32),
-             (640, 400, 64), (300, 64, 7), (300, 64, 128), (257, 16, 96), (4096, 64, 64)]
+             (640, 400, 64), (300, 64, 7), (300, 64, 128), (257, 16, 96), (4096, 64, 64), (1, 128, 128), (40000 + 19, 128, 128)]
 
 
 @pytest.mark.parametrize("N,K,H", LIN_CASES)
@@ -271,6 +271,36 @@ def test_linear_forward_stats_and_grads(N, K, H, pro, w_off):
                                     ws.data_ptr(), _stream()), "wgrad")
     assert_close(dW.cpu().numpy(), dZ.astype(np.float64).T @ Xe, rtol=TOL, what="wgrad")
     assert_close(db.cpu().numpy(), dZ.astype(np.float64).sum(0), rtol=TOL, what="bias grad")
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_split_precision_products_k128_are_fp32_accurate(wide):
+    """The K = H = 128 Linear of BASELINE configs[3] (csrc/linear.hip gnm_lin_split128_kernel): forward with the fused
+    BatchNorm + ReLU prologue and the k-major (dX) form, element by element below 1e-6 x sum_k |x_k||w_k| against fp64."""
+    from gnm import core
+    N, K, H = 8192 + 45, 128, 128
+    rng = np.random.default_rng(22)
+    scale = (lambda shape: np.exp2(rng.integers(-12, 13, shape)).astype(np.float32)) if wide else (lambda shape: np.float32(1))
+    X = (rng.standard_normal((N, K)) * scale((N, K))).astype(np.float32)
+    W = (rng.standard_normal((H, K)) / 11 * scale((H, K))).astype(np.float32)
+    b = rng.standard_normal(H).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    sh = rng.standard_normal(K).astype(np.float32)
+    Xd, Wd, bd, scd, shd = (torch.from_numpy(a).to(DEV) for a in (X, W, b, sc, sh))
+    W64 = W.astype(np.float64)
+    for pro in (None, (scd, shd)):
+        Z = torch.empty(N, H, device=DEV)
+        core._linear(Xd, Wd, 0, bd, Z, N, K, H, pro, None)
+        X64 = (np.maximum(X * sc + sh, 0) if pro else X).astype(np.float64)
+        err = np.abs(Z.cpu().numpy() - (X64 @ W64.T + b)) / (np.abs(X64) @ np.abs(W64).T + np.abs(b))
+        print("K = 128 split-precision forward (prologue %s): max error %.2e of sum |x||w|" % (pro is not None, err.max()))
+        assert err.max() < 1e-6
+    dX = torch.empty(N, K, device=DEV)
+    core._linear(Xd, Wd, 1, None, dX, N, H, K, None, None)
+    X64 = X.astype(np.float64)
+    e2 = np.abs(dX.cpu().numpy() - X64 @ W64) / (np.abs(X64) @ np.abs(W64))
+    print("K = 128 split-precision k-major form: max error %.2e" % e2.max())
+    assert e2.max() < 1e-6
 
 
 @pytest.mark.parametrize("wide", [False, True])
