@@ -1486,6 +1486,152 @@ static int launch_wgrad(const WgArgs& a, int grid, hipStream_t s) {
     return GNM_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// K = H = 128 weight gradient on the bf16 matrix pipe (round 3: the hidden Linears of BASELINE configs[3]; the fp32
+// instruction kernel above runs this shape at 124 us per 256,000 rows with one wave per SIMD).  The contraction index
+// is the batch row, so an operand fragment is "eight consecutive rows of one column" per lane: exactly what a 4-byte
+// load with lane = column delivers (128 contiguous bytes per half-wave), no transpose through LDS.  Both operands are
+// split in registers into three exact bf16 planes (see gnm_lin_split_kernel) and six terms per 16 rows are issued.
+// Eight waves per workgroup: wave (q, rs) owns the 64 x 64 quadrant q of dW and every second 16-row group of the
+// workgroup's row range; the two row halves are added in a fixed order and the workgroup writes the same
+// [H * kw + H] partial the fp32 kernels write, so gnm_reduce_partials_kernel and the workspace are unchanged.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) gnm_wgrad_split128_kernel(const WgArgs p) {
+    constexpr int TILE = 16 * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dump = reinterpret_cast<float*>(smem);                 // [8 waves][4 tiles][16][64] + [8][2][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, hh = lane >> 5;
+    const int q = wave & 3, rs = wave >> 2;
+    const int qi = q >> 1, qj = q & 1;
+    const long long row0 = (long long)blockIdx.x * p.rows_per_block;
+    const long long rows = min((long long)p.N - row0, (long long)p.rows_per_block);
+    const __amdgpu_buffer_rsrc_t rd = gnm_tile_rsrc(p.dZ + row0 * p.ldd, rows, p.ldd, 128);
+    const __amdgpu_buffer_rsrc_t rx = gnm_tile_rsrc(p.X + row0 * p.ldx + p.k0, rows, p.ldx, 128);
+    int dvo[8], xvo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dvo[j] = ((8 * hh + j) * p.ldd + 64 * qi + i) * 4;
+        xvo[j] = ((8 * hh + j) * p.ldx + 64 * qj + i) * 4;
+    }
+    float psc[2], psh[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        psc[b] = p.pro_scale ? p.pro_scale[p.k0 + 64 * qj + 32 * b + i] : 1.f;
+        psh[b] = p.pro_scale ? p.pro_shift[p.k0 + 64 * qj + 32 * b + i] : 0.f;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float dbs[2] = {0.f, 0.f};
+    const int ngroups = rows > 0 ? (int)((rows + 15) / 16) : 0;
+
+    // a group past the end reads zeros (the descriptor's range check covers the scalar offset: see gnm_tile_rsrc)
+    auto load = [&](float (&d)[2][8], float (&x)[2][8], int g) {
+        const int sd = g * 16 * p.ldd * 4, sx = g * 16 * p.ldx * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) d[a][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, dvo[j] + 128 * a, sd, 0));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) x[b][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xvo[j] + 128 * b, sx, 0));
+        }
+    };
+    auto compute = [&](float (&d)[2][8], float (&x)[2][8]) {
+        if (p.pro_scale) {
+            // (a clipped row read zero and the affine map moves it: it meets a zero of dZ)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float v = x[b][j] * psc[b] + psh[b];
+                    x[b][j] = p.pro_relu ? gnm_relu(v) : v;
+                }
+        }
+        lin_bf16x8 dp[2][3], xp[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            dbs[a] += ((d[a][0] + d[a][1]) + (d[a][2] + d[a][3])) + ((d[a][4] + d[a][5]) + (d[a][6] + d[a][7]));
+            u32x4 p1, p2, p3;
+            lin_split8(d[a], p1, p2, p3);
+            dp[a][0] = __builtin_bit_cast(lin_bf16x8, p1); dp[a][1] = __builtin_bit_cast(lin_bf16x8, p2);
+            dp[a][2] = __builtin_bit_cast(lin_bf16x8, p3);
+            lin_split8(x[a], p1, p2, p3);
+            xp[a][0] = __builtin_bit_cast(lin_bf16x8, p1); xp[a][1] = __builtin_bit_cast(lin_bf16x8, p2);
+            xp[a][2] = __builtin_bit_cast(lin_bf16x8, p3);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][0], xp[b][2], acc[a][b], 0, 0, 0);   // small terms first
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][2], xp[b][0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][1], xp[b][1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][0], xp[b][1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][1], xp[b][0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][0], xp[b][0], acc[a][b], 0, 0, 0);
+            }
+    };
+    // two register images: group g + 2 is requested before group g is split and multiplied
+    float dA_[2][8], xA_[2][8], dB_[2][8], xB_[2][8];
+    load(dA_, xA_, rs);
+#pragma nounroll
+    for (int g = rs; g < ngroups; g += 4) {
+        load(dB_, xB_, g + 2);
+        compute(dA_, xA_);
+        load(dA_, xA_, g + 4);
+        compute(dB_, xB_);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // (the last, unused request)
+
+    float* mine = dump + (size_t)wave * 4 * TILE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(a * 2 + b) * TILE + r * 64 + lane] = acc[a][b][r];
+    float* dbdump = dump + (size_t)8 * 4 * TILE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) dbdump[(wave * 2 + a) * 64 + lane] = dbs[a];
+    __syncthreads();
+    float* out = p.partial + (size_t)blockIdx.x * ((size_t)p.H * p.kw + p.H);
+    for (int idx = tid; idx < 4 * 4 * TILE; idx += 512) {
+        const int qq = idx / (4 * TILE);
+        const int rem = idx - qq * (4 * TILE);
+        const int ab = rem / TILE;
+        const int rl = rem - ab * TILE;
+        const int r = rl >> 6, ln = rl & 63;
+        const int row = 64 * (qq >> 1) + 32 * (ab >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int col = 64 * (qq & 1) + 32 * (ab & 1) + (ln & 31);
+        out[(size_t)row * p.kw + col] = dump[(size_t)qq * 4 * TILE + rem] + dump[(size_t)(4 + qq) * 4 * TILE + rem];
+    }
+    for (int idx = tid; idx < 128; idx += 512) {
+        const int qqi = idx >> 6, a = (idx >> 5) & 1, ii = idx & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int wv = 4 * w + 2 * qqi;       // the quadrant with qj = 0 of this row half
+            s += dbdump[(wv * 2 + a) * 64 + ii] + dbdump[(wv * 2 + a) * 64 + 32 + ii];
+        }
+        out[(size_t)p.H * p.kw + idx] = s;
+    }
+}
+
+static int launch_wgrad_split128(const WgArgs& a, int grid, hipStream_t s) {
+    const size_t lds = ((size_t)8 * 4 * 1024 + (size_t)8 * 2 * 64) * 4;
+    GNM_ALLOW_FULL_LDS((&gnm_wgrad_split128_kernel));
+    hipLaunchKernelGGL(gnm_wgrad_split128_kernel, dim3(grid), dim3(512), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 extern "C" int gnm_wgrad_grid(int N) {
     int g = (N + 511) / 512;            // >= 512 rows per block
     if (g > 256) g = 256;               // one block per CU: fewer partials to reduce
@@ -2423,6 +2569,11 @@ extern "C" int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ld
         const int QI = (HT + WI - 1) / WI, QJ = (KT + WJ - 1) / WJ;
         int rc = GNM_ERR_UNSUPPORTED;
         const bool fast = (H % 32) == 0 && N > 0 && !lin_force_generic();
+        // H = 128 and a full 128-column window, 32-bit offsets inside a workgroup's row range: the bf16-pipe kernel
+        if (fast && H == 128 && kw == 128 && !lin_no_split() && (long long)(rpb + 64) * (ldd > ldx ? ldd : ldx) * 4 < (1LL << 31)) {
+            rc = launch_wgrad_split128(a, grid, s);
+            if (rc != GNM_OK) return rc;
+        } else {
 #define GNM_WG_CASE(WI_, WJ_, QI_, QJ_)                                                       \
     if (WI == WI_ && WJ == WJ_ && QI == QI_ && QJ == QJ_)                                     \
         rc = fast ? launch_wgrad_fast<WI_, WJ_, QI_, QJ_>(a, grid, s) : launch_wgrad<WI_, WJ_, QI_, QJ_>(a, grid, s);
@@ -2430,6 +2581,7 @@ extern "C" int gnm_linear_wgrad(const float* dZ, int ldd, const float* X, int ld
         GNM_WG_CASE(2, 1, 1, 1) GNM_WG_CASE(2, 2, 1, 1) GNM_WG_CASE(2, 2, 1, 2)
         GNM_WG_CASE(2, 1, 2, 1) GNM_WG_CASE(2, 2, 2, 1) GNM_WG_CASE(2, 2, 2, 2)
 #undef GNM_WG_CASE
+        }
         if (rc != GNM_OK) return rc;
         const long long stride = (long long)H * kw + H;
         const int count = H * kw + H;

@@ -301,6 +301,23 @@ def test_split_precision_products_k128_are_fp32_accurate(wide):
     e2 = np.abs(dX.cpu().numpy() - X64 @ W64) / (np.abs(X64) @ np.abs(W64))
     print("K = 128 split-precision k-major form: max error %.2e" % e2.max())
     assert e2.max() < 1e-6
+    # dW = dZ^T relu(sc X + sh) (gnm_wgrad_split128_kernel: batch row as the contraction index, 8,237 rows accumulated
+    # in fp32 per workgroup and the workgroups' partials in a fixed order)
+    from gnm._cabi import check, lib
+    G = (rng.standard_normal((N, H)) * scale((N, H))).astype(np.float32)
+    Gd = torch.from_numpy(G).to(DEV)
+    dW, db = torch.empty(H, K, device=DEV), torch.empty(H, device=DEV)
+    ws = torch.empty(int(lib.gnm_wgrad_workspace_floats(N, H, K)), device=DEV)
+    for pro in (False, True):
+        check(lib.gnm_linear_wgrad(Gd.data_ptr(), H, Xd.data_ptr(), K, N, H, K, scd.data_ptr() if pro else None,
+                                   shd.data_ptr() if pro else None, 1 if pro else 0, dW.data_ptr(), K, db.data_ptr(),
+                                   ws.data_ptr(), _stream()), "wgrad")
+        X64 = (np.maximum(X * sc + sh, 0) if pro else X).astype(np.float64)
+        G64 = G.astype(np.float64)
+        e3 = np.abs(dW.cpu().numpy() - G64.T @ X64) / (np.abs(G64).T @ np.abs(X64))
+        print("K = 128 split-precision wgrad (prologue %s): max error %.2e of sum |g||x|" % (pro, e3.max()))
+        assert e3.max() < 2e-6
+        assert_close(db.cpu().numpy(), G64.sum(0), rtol=TOL, what="bias grad")
 
 
 @pytest.mark.parametrize("wide", [False, True])
