@@ -42,14 +42,35 @@ struct LinArgs {
     int stage_out;           // gnm_lin_kernel: the launch reserved LDS for the output staging image
 };
 
+// First tile of a wave in the strided tile walk (stride = all active waves of the launch).  Numbering the waves
+// workgroup by workgroup hands the remainder tiles (ntiles mod stride) to the FIRST workgroups only -- at the headline
+// shape 12,800 tiles over 3,072 waves: five tiles for every wave of workgroups 0-42 and four for the rest, and the
+// launch lasts as long as those 43 CUs need for 60 tiles while the other 213 have 48.  Numbered slot-major instead
+// (one wave of every group of every workgroup first, on different SIMDs, then the next ...) every CU gets 50.
+// `groups` groups of four waves per workgroup, `rows` groups in the launch; a launch whose last workgroup is not full
+// (rows != groups * gridDim.x: small N) keeps the plain numbering, and waves past the last row get no tile.
+__device__ __forceinline__ int lin_first_tile(int wave, int groups, int rows) {
+    const int grp = wave >> 2, nwg = (int)gridDim.x, b = (int)blockIdx.x;
+    if (rows == groups * nwg) {
+        const int slot = ((wave & 3) + grp * (groups == 2 ? 2 : 1)) & 3;
+        return (slot * groups + grp) * nwg + b;
+    }
+    const int gw = b * groups * 4 + wave;
+    return gw < 4 * rows ? gw : 0x3fffffff;
+}
+
 #ifdef GNM_LIN_TUNING
 static unsigned long long* g_lin_stamps = nullptr;
 extern "C" void gnm_debug_set_lin_stamps(void* p) { g_lin_stamps = reinterpret_cast<unsigned long long*>(p); }
 #define GNM_LSTAMP(k)                                                                                         \
     if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
         p.stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime();
+#define GNM_RSTAMP(k)      /* gnm_linear_bwd_rz_kernel: eight waves per workgroup */                        \
+    if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
+        p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define GNM_LSTAMP(k)
+#define GNM_RSTAMP(k)
 #endif
 
 template <int KC, int HT>
@@ -102,7 +123,7 @@ __global__ void __launch_bounds__(256) gnm_lin_kernel(const LinArgs p) {
     }
     const int c4 = lane % C4;            // loop-invariant: 64 % C4 == 0
 
-    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+    for (int t = lin_first_tile(wave, 1, gridDim.x); t < ntiles; t += gridDim.x * 4) {
         const int r0 = t * 32;
         f32x16 acc[HT];
 #pragma unroll
@@ -289,7 +310,7 @@ __global__ void __launch_bounds__(256) gnm_lin_fast_kernel(const LinArgs p) {
     const int nlast = p.N - 1;
 
     float4 raw[NLD];
-    int t = blockIdx.x * 4 + wave;
+    int t = lin_first_tile(wave, 1, gridDim.x);
     if (t < ntiles) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
@@ -505,7 +526,7 @@ __global__ void __launch_bounds__(256) gnm_lin_stream_kernel(const LinArgs p) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, j * in_step, 0);
     };
-    int t = blockIdx.x * 4 + wave;
+    int t = lin_first_tile(wave, 1, gridDim.x);
     load_tile(t);                                 // the first tile arrives while the weight is staged
 
     // weight -> LDS as Wt[k][h].  torch layout W[h][k]: a lane takes 4 consecutive k of one h (16-B global read) and
@@ -744,8 +765,8 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
     }
     // waves are numbered across the launch; groups of four own one row of statistics partials, exactly the tile ->
     // row map of the 4-wave kernels; waves past the last row (a grid that is not a multiple of 3) take no tiles
-    const int gw = blockIdx.x * NW + wave;
-    const int ntiles = (gw < 4 * p.stat_rows) ? (p.N + 31) / 32 : 0;
+    const int gw = lin_first_tile(wave, NW / 4, p.stat_rows);
+    const int ntiles = (p.N + 31) / 32;
     const int tstride = 4 * p.stat_rows;
     const int in_voff = (lrow0 * p.ldx + 4 * c4) * 4;
     const int in_step = RSTEP * p.ldx * 4;
@@ -978,8 +999,8 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): nothing from the preamble is pending inside the tile loop
     __syncthreads();
 
-    const int gw = blockIdx.x * NW + wave;
-    const int ntiles = (gw < 4 * p.stat_rows) ? (p.N + 31) / 32 : 0;
+    const int gw = lin_first_tile(wave, NW / 4, p.stat_rows);
+    const int ntiles = (p.N + 31) / 32;
     const int tstride = 4 * p.stat_rows;
     const int in_voff = (i * p.ldx + 32 * h) * 4;
     for (int e = lane; e < 2 * HP; e += 64) wst[e] = 0.0;       // (wave-private: no barrier needed)
@@ -1707,6 +1728,8 @@ struct LbArgs {
     int N, K, H;
     int pro_relu;
     unsigned long long* stamps;   // tuning builds only, as LinArgs::stamps
+    const float* bias;            // gnm_linear_bwd_rz_kernel only: Z is not read but recomputed as f(X) W^T + bias
+    int part_rows;                // ... and the rows of `partial` / `s_partial` its launch writes (two per workgroup)
 };
 
 // NARROW: K < 32 (the first Linear of layer 0, K = F0): one zero-padded 32-column tile, guarded scalar
@@ -1803,7 +1826,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
 
     const int ntiles = (p.N + 31) / 32;
     const int nlast = p.N - 1;
-    for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+    for (int t = lin_first_tile(wave, 1, gridDim.x); t < ntiles; t += gridDim.x * 4) {
         const int r0 = t * 32;
         GNM_LSTAMP(2 + 5 * min(tk, 11))
         // ---- all global loads of the tile first -------------------------------------
@@ -1812,7 +1835,11 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_fused_kernel(const LbAr
         for (int j = 0; j < NLD; ++j) {
             const int grow = min(r0 + lrow0 + j * RSTEP, nlast);
             g4[j] = *reinterpret_cast<const float4*>(p.G + (size_t)grow * p.ldg + 4 * c4);
+#ifdef GNM_EXP_NOZ          // timing experiment only (wrong results): what the kernel costs without the Z stream
+            z4[j] = g4[j];
+#else
             z4[j] = *reinterpret_cast<const float4*>(p.Z + (size_t)grow * p.ldz + 4 * c4);
+#endif
         }
         if constexpr (SAMEZ) {
             mu = *reinterpret_cast<const float4*>(p.mean + 4 * c4);
@@ -2190,7 +2217,11 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             g4[j] = __builtin_amdgcn_raw_buffer_load_b128(rg, gz_voff_g, j * gz_step_g, 0);
+#ifdef GNM_EXP_NOZ
+            z4[j] = g4[j];
+#else
             z4[j] = __builtin_amdgcn_raw_buffer_load_b128(rz, gz_voff_z, j * gz_step_z, 0);
+#endif
         }
     };
     auto do_tile = [&](int t, int t_next) {
@@ -2326,7 +2357,7 @@ __global__ void __launch_bounds__(256, 2) gnm_linear_bwd_pipe_kernel(const LbArg
         __builtin_amdgcn_wave_barrier();
     };
     {
-        int t = blockIdx.x * 4 + wave;
+        int t = lin_first_tile(wave, 1, gridDim.x);
         load_gz(t);
         if (t < ntiles) {
             do_tile(t, t + tstride);                  // peeled
@@ -2397,6 +2428,451 @@ static int launch_lb(const LbArgs& a, int grid, hipStream_t s) {
     return GNM_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// The fused backward of a K = H = 64 Linear WITHOUT the Z stream (round 3).  The kernels above read four [N,64] arrays
+// (G, Z, X in; dX out = 420 MB per launch of the headline batch) and Z -- this Linear's own output, needed only for
+// xhat = (Z - mean) rstd inside the BatchNorm backward -- is a function of X, which the pass reads anyway for the weight
+// gradient: Z = f(X) W^T + b is recomputed on the bf16 matrix pipe with exactly the instruction sequence of
+// gnm_lin_split_kernel (48 MFMAs per 32 rows, the same values bit for bit) and a quarter of the traffic is gone.
+// (Timing the old kernels with the Z loads stubbed out gave 96.5 -> 85.8 us and 92.5 -> 72.6 us: the bound of this form.)
+// What changes around that:
+//  * the recomputed Z arrives in the accumulator layout (lane = column, 16 rows in registers), so G is loaded in that
+//    layout too (4-byte loads, 128 contiguous bytes per half-wave) and dZ is formed there; the BatchNorm coefficients
+//    are per-lane scalars;
+//  * the weight-gradient product takes its dZ operand from those registers (no column reads of the LDS image) and its
+//    X operand from lane = column loads of the rows in the same order; WG16: both are split into three bf16 planes and
+//    the product runs as 48 bf16 instructions instead of 64 fp32 ones (a quarter of the matrix-pipe time);
+//  * only dgrad still needs the transpose: dZ goes through the wave's LDS image once, row-wise out;
+//  * G AND the row-wise X fragments of the wave's next tile are requested before the weight-gradient product (the
+//    registers Z used to occupy), in both forms -- the statistics form above had no room for that;
+//  * eight waves per workgroup share the two weight images (forward orientation for Z, k-major for dgrad: 48 KB) and the
+//    workgroup writes TWO rows of partials (waves 0-3, 4-7), so gnm_linear_bwd_grid(N) rows exist as before.
+// SAMEZ: the second Linear of an MLP (the lower BatchNorm's input is X, its affine the prologue) -- ReLU mask and that
+// BatchNorm's backward sums on the dX accumulators, as in gnm_linear_bwd_fused_kernel.  !SAMEZ: no lower statistics.
+// ---------------------------------------------------------------------------------
+static constexpr int kRzWaves = 8;
+
+template <bool SAMEZ, bool WG16>
+__global__ void __launch_bounds__(kRzWaves * 64) gnm_linear_bwd_rz_kernel(const LbArgs p) {
+    constexpr int KP = 64, HP = 64, XS = 68, EW = 512, NW = kRzWaves, NT = NW * 64, TILE = 16 * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* Wf = reinterpret_cast<u32x4*>(smem);                   // [3][EW]: (m, c, lane = 32 kg + n) = W[32c+n][8m+32kg+j]
+    u32x4* Wb = Wf + 3 * EW;                                      // [3][EW]: (m, c, lane = 32 kg + n) = W[8m+32kg+j][32c+n]
+    float* Xs_all = reinterpret_cast<float*>(smem + (size_t)6 * EW * 16);     // [NW][32][XS]
+    float* coef = Xs_all + NW * 32 * XS;                          // [6][64]: mean, rstd, cA, m1, m2, bias
+    float* psv = coef + 6 * 64;                                   // [2][64]: prologue scale, shift
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float* Xs = Xs_all + wave * 32 * XS;
+    const bool pro = p.pro_scale != nullptr;
+    GNM_RSTAMP(0)
+    for (int e = tid; e < EW; e += NT) {
+        const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) & 1, m = e >> 7;
+        float f[8];
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = p.W[(size_t)(32 * c + n) * p.ldw + 8 * m + 32 * kg + j];
+        lin_split8(f, p1, p2, p3);
+        Wf[e] = p1; Wf[EW + e] = p2; Wf[2 * EW + e] = p3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = p.W[(size_t)(8 * m + 32 * kg + j) * p.ldw + 32 * c + n];
+        lin_split8(f, p1, p2, p3);
+        Wb[e] = p1; Wb[EW + e] = p2; Wb[2 * EW + e] = p3;
+    }
+    for (int idx = tid; idx < 64; idx += NT) {
+        coef[idx] = p.mean[idx]; coef[64 + idx] = p.rstd[idx]; coef[128 + idx] = p.cA[idx];
+        coef[192 + idx] = p.m1[idx]; coef[256 + idx] = p.m2[idx]; coef[320 + idx] = p.bias ? p.bias[idx] : 0.f;
+        psv[idx] = pro ? p.pro_scale[idx] : 1.f;
+        psv[64 + idx] = pro ? p.pro_shift[idx] : 0.f;
+    }
+    // SAMEZ: the lower BatchNorm's mean / rstd and the lane's running sums live in LDS too (with them and the prologue
+    // vectors in registers the statistics form spilled 126-191 registers; the plain form sits at 256 exactly)
+    float psc[2], psh[2];                                         // (plain form: registers -- from LDS it spilled 34)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        psc[b] = (pro && !SAMEZ) ? p.pro_scale[32 * b + i] : 1.f;
+        psh[b] = (pro && !SAMEZ) ? p.pro_shift[32 * b + i] : 0.f;
+    }
+    float* lstat = psv + 2 * 64;                                  // [2][64]: lower mean, rstd
+    float* lsum = lstat + 2 * 64 + wave * 4 * 64;                 // [NW][2 c][2][64 lanes]: this wave's sums
+    if constexpr (SAMEZ) {
+        for (int idx = tid; idx < 64; idx += NT) {
+            lstat[idx] = p.s_mean[idx];
+            lstat[64 + idx] = p.s_rstd[idx];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lsum[q * 64 + lane] = 0.f;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): nothing from the preamble is pending inside the tile loop
+    __syncthreads();
+    GNM_RSTAMP(1)
+    int tk = 0;
+
+    f32x16 wacc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wacc[a][b][r] = 0.f;
+    float dbacc[2] = {0.f, 0.f};
+
+    const int gw = lin_first_tile(wave, NW / 4, p.part_rows);
+    const int ntiles = (p.N + 31) / 32;
+    const int tstride = p.part_rows * 4;
+    const int g_voff = (4 * h * p.ldg + i) * 4;                   // G[row(r, h)][32 a + i], row(r, h) = (r&3) + 8(r>>2) + 4h
+    const int xa_voff = (i * p.ldx + 32 * h) * 4;                 // X[i][32 h + 8 m + 0..7]: the forward's A fragments
+    const int xc_voff = (4 * h * p.ldx + i) * 4;                  // X[row(r, h)][32 b + i]
+    const int out_voff = ((lane >> 4) * p.lda + 4 * (lane & 15)) * 4, out_step = 4 * p.lda * 4;
+
+    float g[2][16];
+    u32x4 xa[4][2];
+    auto load_next_x = [&](int tile) {
+        const long long row0 = (long long)tile * 32;
+        const long long rows = min((long long)p.N - row0, 32LL);
+        const __amdgpu_buffer_rsrc_t rx = gnm_tile_rsrc(p.X + row0 * p.ldx, rows, p.ldx, KP);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            xa[m][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, xa_voff, 32 * m, 0);
+            xa[m][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, xa_voff, 32 * m + 16, 0);
+        }
+    };
+    auto load_next_g = [&](int tile) {
+        const long long row0 = (long long)tile * 32;
+        const long long rows = min((long long)p.N - row0, 32LL);
+        const __amdgpu_buffer_rsrc_t rg = gnm_tile_rsrc(p.G + row0 * p.ldg, rows, p.ldg, HP);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                g[a][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, g_voff + 128 * a, ((r & 3) + 8 * (r >> 2)) * p.ldg * 4, 0));
+    };
+    auto do_tile = [&](int t, int t_next) {
+        const int r0 = t * 32;
+        const int rows = min(p.N - r0, 32);
+        GNM_RSTAMP(2 + 6 * min(tk, 9))
+        // ---- Z = f(X) W^T (+ bias below): gnm_lin_split_kernel's sequence ------------------------------------
+        f32x16 dz[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[c][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 v0 = __builtin_bit_cast(float4, xa[m][0]), v1 = __builtin_bit_cast(float4, xa[m][1]);
+            float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (pro) {
+                const int k0 = 32 * h + 8 * m;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float4 sc = *reinterpret_cast<const float4*>(psv + k0 + 4 * q);
+                    const float4 sh = *reinterpret_cast<const float4*>(psv + 64 + k0 + 4 * q);
+                    f[4 * q + 0] = f[4 * q + 0] * sc.x + sh.x; f[4 * q + 1] = f[4 * q + 1] * sc.y + sh.y;
+                    f[4 * q + 2] = f[4 * q + 2] * sc.z + sh.z; f[4 * q + 3] = f[4 * q + 3] * sc.w + sh.w;
+                }
+                if (p.pro_relu) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = gnm_relu(f[j]);
+                }
+            }
+            u32x4 A1, A2, A3;
+            lin_split8(f, A1, A2, A3);
+            const lin_bf16x8 a1 = __builtin_bit_cast(lin_bf16x8, A1), a2 = __builtin_bit_cast(lin_bf16x8, A2),
+                             a3 = __builtin_bit_cast(lin_bf16x8, A3);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int e = (m * 2 + c) * 64 + lane;
+                const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wf[e]), b2 = __builtin_bit_cast(lin_bf16x8, Wf[EW + e]),
+                                 b3 = __builtin_bit_cast(lin_bf16x8, Wf[2 * EW + e]);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, dz[c], 0, 0, 0);
+            }
+        }
+        GNM_RSTAMP(3 + 6 * min(tk, 9))
+        // ---- dZ = cA (G - m1 - xhat m2) on the accumulators; rows past N are zero; image for dgrad ------------
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int col = 32 * a + i;
+            const float mu = coef[col], rs = coef[64 + col], ca = coef[128 + col], a1 = coef[192 + col],
+                        a2 = coef[256 + col], bz = coef[320 + col];
+            float dsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float z = dz[a][r] + bz;
+                float d = ca * (g[a][r] - a1 - (z - mu) * rs * a2);
+                if (lrow >= rows) d = 0.f;
+                dz[a][r] = d;
+                dsum += d;
+                Xs[lrow * XS + col] = d;
+            }
+            dbacc[a] += dsum;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // X in the accumulators' row order (wgrad operand; SAMEZ: the values under the dX accumulators): in flight
+        // during the dgrad MFMAs (cache hits: the tile was read row-wise for Z)
+        float xv[16][2];
+        {
+            const __amdgpu_buffer_rsrc_t rx = gnm_tile_rsrc(p.X + (size_t)r0 * p.ldx, rows, p.ldx, KP);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    xv[r][b] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xc_voff + 128 * b, ((r & 3) + 8 * (r >> 2)) * p.ldx * 4, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        GNM_RSTAMP(4 + 6 * min(tk, 9))
+        // ---- dX = dZ W -------------------------------------------------------------------------------------------
+        f32x16 dacc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[c][r] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 v0 = *reinterpret_cast<const float4*>(Xs + i * XS + 32 * h + 8 * m);
+            const float4 v1 = *reinterpret_cast<const float4*>(Xs + i * XS + 32 * h + 8 * m + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            u32x4 A1, A2, A3;
+            lin_split8(f, A1, A2, A3);
+            const lin_bf16x8 x1 = __builtin_bit_cast(lin_bf16x8, A1), x2 = __builtin_bit_cast(lin_bf16x8, A2),
+                             x3 = __builtin_bit_cast(lin_bf16x8, A3);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int e = (m * 2 + c) * 64 + lane;
+                const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wb[e]), b2 = __builtin_bit_cast(lin_bf16x8, Wb[EW + e]),
+                                 b3 = __builtin_bit_cast(lin_bf16x8, Wb[2 * EW + e]);
+                dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b3, dacc[c], 0, 0, 0);
+                dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, b1, dacc[c], 0, 0, 0);
+                dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b2, dacc[c], 0, 0, 0);
+                dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b2, dacc[c], 0, 0, 0);
+                dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b1, dacc[c], 0, 0, 0);
+                dacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b1, dacc[c], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // the dZ image has been read
+        GNM_RSTAMP(5 + 6 * min(tk, 9))
+        // ---- dX out (SAMEZ: masked by the lower ReLU, and that BatchNorm's backward sums) ---------------------------
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                float gg = dacc[c][r];
+                if constexpr (SAMEZ) {
+                    const float z = xv[r][c];
+                    if (!(z * psv[32 * c + i] + psv[64 + 32 * c + i] > 0.f)) gg = 0.f;
+                    dacc[c][r] = gg;
+                }
+                Xs[lrow * XS + 32 * c + i] = gg;
+            }
+        if constexpr (SAMEZ) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float lmu = lstat[32 * c + i], lrs = lstat[64 + 32 * c + i];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((r & 3) + 8 * (r >> 2) + 4 * h < rows) {
+                        s1 += dacc[c][r];
+                        s2 += dacc[c][r] * ((xv[r][c] - lmu) * lrs);
+                    }
+                }
+                lsum[(2 * c + 0) * 64 + lane] += s1;
+                lsum[(2 * c + 1) * 64 + lane] += s2;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            const __amdgpu_buffer_rsrc_t rd = gnm_tile_rsrc(p.dA + (size_t)r0 * p.lda, rows, p.lda, KP);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int idx = lane + 64 * st;
+                const int row = idx >> 4, oc = idx & 15;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(Xs + row * XS + 4 * oc);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rd, out_voff + st * out_step, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        GNM_RSTAMP(6 + 6 * min(tk, 9))
+        // the next tile: G before the weight-gradient product; the row-wise X fragments too where the registers allow it
+        // (SAMEZ carries eight more per-lane values through the tile and spilled 126 with both in flight: X follows the product)
+        load_next_g(t_next);                      // past the wave's last tile: empty descriptors, no traffic
+        if constexpr (!SAMEZ) load_next_x(t_next);
+        // ---- dW += dZ^T f(X): both operands from registers, batch rows in the accumulators' order ---------------------
+        if constexpr (WG16) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                lin_bf16x8 dp[2][3], xp[2][3];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float f[8];
+                    u32x4 p1, p2, p3;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = dz[a][8 * m + j];
+                    lin_split8(f, p1, p2, p3);
+                    dp[a][0] = __builtin_bit_cast(lin_bf16x8, p1); dp[a][1] = __builtin_bit_cast(lin_bf16x8, p2);
+                    dp[a][2] = __builtin_bit_cast(lin_bf16x8, p3);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float x = xv[8 * m + j][a];
+                        if (pro) {
+                            x = SAMEZ ? x * psv[32 * a + i] + psv[64 + 32 * a + i] : x * psc[a] + psh[a];
+                            if (p.pro_relu) x = gnm_relu(x);
+                        }
+                        f[j] = x;
+                    }
+                    lin_split8(f, p1, p2, p3);
+                    xp[a][0] = __builtin_bit_cast(lin_bf16x8, p1); xp[a][1] = __builtin_bit_cast(lin_bf16x8, p2);
+                    xp[a][2] = __builtin_bit_cast(lin_bf16x8, p3);
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][0], xp[b][2], wacc[a][b], 0, 0, 0);
+                        wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][2], xp[b][0], wacc[a][b], 0, 0, 0);
+                        wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][1], xp[b][1], wacc[a][b], 0, 0, 0);
+                        wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][0], xp[b][1], wacc[a][b], 0, 0, 0);
+                        wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][1], xp[b][0], wacc[a][b], 0, 0, 0);
+                        wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dp[a][0], xp[b][0], wacc[a][b], 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx) {
+                float xf[2];
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    float x = xv[sidx][b];
+                    if (pro) {
+                        x = SAMEZ ? x * psv[32 * b + i] + psv[64 + 32 * b + i] : x * psc[b] + psh[b];
+                        if (p.pro_relu) x = gnm_relu(x);
+                    }
+                    xf[b] = x;
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        wacc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[a][sidx], xf[b], wacc[a][b], 0, 0, 0);
+            }
+        }
+        if constexpr (SAMEZ) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_next_x(t_next);
+        }
+        GNM_RSTAMP(7 + 6 * min(tk, 9))
+        ++tk;
+    };
+    {
+        int t = gw;
+        load_next_x(t);
+        load_next_g(t);
+        if (t < ntiles) {
+            do_tile(t, t + tstride);                  // peeled (see gnm_linear_bwd_pipe_kernel)
+            for (t += tstride; t < ntiles; t += tstride) do_tile(t, t + tstride);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    GNM_RSTAMP(62)
+
+    // ---- lower-BatchNorm sums: two rows of partials per workgroup (waves 0-3, 4-7), fixed order ----
+    if constexpr (SAMEZ) {
+        __syncthreads();
+        double* sred = reinterpret_cast<double*>(smem);           // [NW][2][KP]
+        float cs1[2], cs2[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            cs1[c] = lsum[(2 * c + 0) * 64 + lane];
+            cs2[c] = lsum[(2 * c + 1) * 64 + lane];
+        }
+        __syncthreads();                                          // (sred overlays nothing of lsum, but the weight images)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {                             // the two half-waves hold the same columns
+            double d1 = (double)cs1[c], d2 = (double)cs2[c];
+            d1 += __shfl_xor(d1, 32, 64);
+            d2 += __shfl_xor(d2, 32, 64);
+            if (h == 0) {
+                sred[(wave * 2 + 0) * KP + 32 * c + i] = d1;
+                sred[(wave * 2 + 1) * KP + 32 * c + i] = d2;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * 2 * KP; idx += NT) {
+            const int grp = idx / (2 * KP), rest = idx - grp * 2 * KP;
+            const int which = rest / KP, col = rest - which * KP;
+            const int row = blockIdx.x * 2 + grp;
+            if (row >= p.part_rows) continue;
+            double sum = 0.0;
+            for (int w = 4 * grp; w < 4 * grp + 4; ++w) sum += sred[(w * 2 + which) * KP + col];
+            p.s_partial[((size_t)row * 2 + which) * p.K + col] = sum;
+        }
+    }
+    // ---- dW / db: the waves of each half in a fixed order ----
+    __syncthreads();
+    float* dump = reinterpret_cast<float*>(smem);                 // [NW][4][16][64] + [NW][2][64]
+    float* mine = dump + (size_t)wave * 4 * TILE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(a * 2 + b) * TILE + r * 64 + lane] = wacc[a][b][r];
+    float* dbdump = dump + (size_t)NW * 4 * TILE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) dbdump[(wave * 2 + a) * 64 + lane] = dbacc[a];
+    __syncthreads();
+    for (int idx = tid; idx < 2 * 4 * TILE; idx += NT) {
+        const int grp = idx / (4 * TILE), rem = idx - grp * 4 * TILE;
+        const int prow = blockIdx.x * 2 + grp;
+        if (prow >= p.part_rows) continue;
+        const int ab = rem / TILE;
+        const int rl = rem - ab * TILE;
+        const int r = rl >> 6, ln = rl & 63;
+        const int a = ab >> 1, b = ab & 1;
+        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int col = 32 * b + (ln & 31);
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += dump[(size_t)(4 * grp + w) * 4 * TILE + rem];
+        p.partial[(size_t)prow * ((size_t)HP * KP + HP) + (size_t)row * KP + col] = sum;
+    }
+    for (int idx = tid; idx < 2 * 64; idx += NT) {
+        const int grp = idx >> 6, a = (idx >> 5) & 1, ii = idx & 31;
+        const int prow = blockIdx.x * 2 + grp;
+        if (prow >= p.part_rows) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += dbdump[((4 * grp + w) * 2 + a) * 64 + ii] + dbdump[((4 * grp + w) * 2 + a) * 64 + 32 + ii];
+        p.partial[(size_t)prow * ((size_t)HP * KP + HP) + (size_t)HP * KP + 32 * a + ii] = sum;
+    }
+    GNM_RSTAMP(63)
+}
+
+template <bool SAMEZ, bool WG16>
+static int launch_lb_rz(const LbArgs& a, int grid, hipStream_t s) {
+    size_t lds = (size_t)6 * 512 * 16 + (size_t)kRzWaves * 32 * 68 * 4 + (size_t)(8 + 2 + kRzWaves * 4) * 64 * 4;
+    const size_t dump = ((size_t)kRzWaves * 4 * 1024 + (size_t)kRzWaves * 2 * 64) * 4;
+    if (dump > lds) lds = dump;
+    GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_rz_kernel<SAMEZ, WG16>));
+    hipLaunchKernelGGL((gnm_linear_bwd_rz_kernel<SAMEZ, WG16>), dim3((grid + 1) / 2), dim3(kRzWaves * 64), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 extern "C" int gnm_linear_bwd_grid(int N) {
     int g = ((N + 31) / 32 + 3) / 4;
     static const int cap = gnm_env_int("GNM_LINBWD_GRID", 512);   // tuning knob
@@ -2438,6 +2914,7 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
     a.G = G; a.Z = Z; a.X = X; a.W = W; a.mean = mean; a.rstd = rstd; a.cA = cA; a.m1 = m1; a.m2 = m2;
     a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dA = dA; a.partial = workspace;
     a.ldg = ldg; a.ldz = ldz; a.ldx = ldx; a.ldw = ldw; a.lda = lda; a.N = N; a.K = K; a.H = H; a.pro_relu = pro_relu;
+    a.bias = nullptr; a.part_rows = 0;
 #ifdef GNM_LIN_TUNING
     a.stamps = g_lin_stamps;
 #else
@@ -2470,6 +2947,61 @@ extern "C" int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int
                    : (sZ ? launch_lb<2, 2, true>(a, grid, s) : launch_lb<2, 2, false>(a, grid, s));
     if (rc != GNM_OK) return rc;
     if (!dW) return GNM_OK;      // deferred: the partials stay in `workspace` for gnm_reduce_partials_multi
+    const long long stride = (long long)H * K + H;
+    const int count = H * K + H;
+    hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 31) / 32), dim3(1024), 0, s, workspace, grid, stride,
+                       H, K, 0, dW, lddw, db);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// gnm_linear_bwd_fused for a Linear whose output Z the caller does NOT pass: Z = f(X) W^T + bias is recomputed
+// (gnm_linear_bwd_rz_kernel).  K = H = 64 with dA wanted, and either no lower BatchNorm (sZ = NULL) or the lower
+// BatchNorm's input being X with the prologue as its affine (the two Linears of the headline model's MLPs); anything
+// else returns GNM_ERR_UNSUPPORTED and the caller takes gnm_linear_bwd_fused with the stored Z.  Workspace, partial
+// rows and the deferred reduction (dW = NULL) are those of gnm_linear_bwd_fused.
+extern "C" int gnm_linear_bwd_fused_rz(const float* G, int ldg, const float* bias, const float* mean, const float* rstd,
+                                       const float* cA, const float* m1, const float* m2, const float* X, int ldx,
+                                       const float* pro_scale, const float* pro_shift, int pro_relu, const float* W,
+                                       int ldw, float* dA, int lda, float* dW, int lddw, float* db, float* workspace,
+                                       int N, int K, int H, const float* sZ, int ldsz, const float* s_scale,
+                                       const float* s_shift, const float* s_mean, const float* s_rstd,
+                                       double* s_partial, void* stream) {
+    static const bool off = gnm_env_int("GNM_LINBWD_NO_RZ", 0) != 0;
+    static const bool wg16 = gnm_env_int("GNM_LINBWD_WG16", 1) != 0;     // A/B knob: weight gradient on the bf16 pipe
+    if (off || N <= 0 || K != 64 || H != 64 || !dA || lin_force_generic() || linbwd_no_split()) return GNM_ERR_UNSUPPORTED;
+    if ((ldx & 3) || (lda & 3)) return GNM_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dA)) & 15) return GNM_ERR_UNSUPPORTED;
+    if ((long long)32 * (ldg > ldx ? (ldg > lda ? ldg : lda) : (ldx > lda ? ldx : lda)) * 4 >= (1LL << 31)) return GNM_ERR_UNSUPPORTED;
+    const bool samez = sZ != nullptr;
+    // the statistics form is correct and tested but measured BEHIND the kernel that reads Z (103.7 vs 98.6 us at the
+    // headline shape: its extra per-lane state lives in LDS); the plain form is ahead (87.9 vs 90.9 us).  GNM_LINBWD_RZ_STATS=1
+    // enables it for A/B timing and for its test.
+    static const bool rz_stats = gnm_env_int("GNM_LINBWD_RZ_STATS", 0) != 0;
+    if (samez && !rz_stats) return GNM_ERR_UNSUPPORTED;
+    if (samez && !(sZ == X && ldsz == ldx && s_scale == pro_scale && s_shift == pro_shift && pro_scale && pro_relu &&
+                   s_partial && s_mean && s_rstd))
+        return GNM_ERR_UNSUPPORTED;
+    LbArgs a;
+    a.sZ = sZ; a.s_scale = s_scale; a.s_shift = s_shift; a.s_mean = s_mean; a.s_rstd = s_rstd;
+    a.s_partial = s_partial; a.ldsz = ldsz;
+    a.G = G; a.Z = nullptr; a.X = X; a.W = W; a.mean = mean; a.rstd = rstd; a.cA = cA; a.m1 = m1; a.m2 = m2;
+    a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.dA = dA; a.partial = workspace;
+    a.ldg = ldg; a.ldz = 0; a.ldx = ldx; a.ldw = ldw; a.lda = lda; a.N = N; a.K = K; a.H = H; a.pro_relu = pro_relu;
+#ifdef GNM_LIN_TUNING
+    a.stamps = g_lin_stamps;
+#else
+    a.stamps = nullptr;
+#endif
+    a.bias = bias;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = gnm_linear_bwd_grid(N);
+    a.part_rows = grid;
+    int rc;
+    if (samez) rc = wg16 ? launch_lb_rz<true, true>(a, grid, s) : launch_lb_rz<true, false>(a, grid, s);
+    else rc = wg16 ? launch_lb_rz<false, true>(a, grid, s) : launch_lb_rz<false, false>(a, grid, s);
+    if (rc != GNM_OK) return rc;
+    if (!dW) return GNM_OK;
     const long long stride = (long long)H * K + H;
     const int count = H * K + H;
     hipLaunchKernelGGL(gnm_reduce_partials_kernel, dim3((count + 31) / 32), dim3(1024), 0, s, workspace, grid, stride,

@@ -14,12 +14,12 @@
 
 // ---------------------------------------------------------------------------------
 // column-partial reduction shared by the two finalize kernels.
-// partial: [nblk][2][H] doubles.  A workgroup owns a slice of CW = 16 columns (both the
-// "sum" and the "second sum" halves), so the grid is H/16 workgroups and each streams only
-// its 2*16 columns of every partial row: one workgroup reading all ~0.8 MB of partials is
-// limited to a single CU's bandwidth (~16 us), H/16 of them are not.  Fixed summation order.
+// partial: [nblk][2][H] doubles.  A workgroup owns a slice of CW = 4 columns (both the "sum" and the "second sum"
+// halves), so the grid is H/4 workgroups of 128 row groups each: with ~768 partial rows a thread has six values to
+// fetch and requests them all at once.  (One workgroup reading all ~0.8 MB of partials took ~16 us; H/16 workgroups
+// whose threads walked 24 rows in dependent batches of four 6.7 us -- twenty such launches per step.)  Fixed order.
 // ---------------------------------------------------------------------------------
-static constexpr int kFinCols = 16;
+static constexpr int kFinCols = 4;
 
 // workgroup size of the one-workgroup-per-graph kernels: 256 threads when there are plenty of graphs, 1024 when a
 // batch of few large graphs (e.g. 256 x 1000 nodes) would otherwise put 4 waves on each CU
@@ -27,29 +27,41 @@ static inline int per_graph_threads(int B) { return B >= 1024 ? 256 : 1024; }
 
 __device__ __forceinline__ void reduce_partials_slice(const double* partial, int nblk, int H, int c0, double* lds,
                                                       double* tot /*[2*kFinCols]*/) {
-    constexpr int NC = 2 * kFinCols;              // columns handled here: 16 of each half
-    const int tid = threadIdx.x;                  // 1024 threads = 32 row groups x 32 columns
+    constexpr int NC = 2 * kFinCols;              // columns handled here: 4 of each half
+    const int tid = threadIdx.x;                  // 1024 threads = 128 row groups x 8 columns
     const int g = tid / NC, cc = tid - g * NC;
     const int which = cc / kFinCols, c = c0 + (cc - which * kFinCols);
     constexpr int groups = 1024 / NC;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    constexpr int U = 8;
+    double s[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s[u] = 0.0;
     if (c < H) {
         const double* base = partial + (size_t)which * H + c;
-        int b = g;
-        for (; b + 3 * groups < nblk; b += 4 * groups) {
-            const double v0 = base[(size_t)(b + 0 * groups) * 2 * H], v1 = base[(size_t)(b + 1 * groups) * 2 * H];
-            const double v2 = base[(size_t)(b + 2 * groups) * 2 * H], v3 = base[(size_t)(b + 3 * groups) * 2 * H];
-            s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        for (int b = g; b < nblk; b += U * groups) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int bb = b + u * groups;
+                v[u] = bb < nblk ? base[(size_t)bb * 2 * H] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) s[u] += v[u];
         }
-        for (; b < nblk; b += groups) s0 += base[(size_t)b * 2 * H];
     }
-    lds[g * NC + cc] = (s0 + s1) + (s2 + s3);
+    lds[g * NC + cc] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
-    if (tid < NC) {
-        double t = 0.0;
-        for (int gg = 0; gg < groups; ++gg) t += lds[gg * NC + tid];
-        tot[tid] = t;
+    // 128 row groups per column: four threads take 32 each, then one adds the four
+    constexpr int Q = 4, GQ = groups / Q;
+    double t = 0.0;
+    if (tid < Q * NC) {
+        const int qq = tid / NC, col = tid - qq * NC;
+        for (int gg = qq * GQ; gg < (qq + 1) * GQ; ++gg) t += lds[gg * NC + col];
     }
+    __syncthreads();
+    if (tid < Q * NC) lds[tid] = t;
+    __syncthreads();
+    if (tid < NC) tot[tid] = (lds[tid] + lds[NC + tid]) + (lds[2 * NC + tid] + lds[3 * NC + tid]);
     __syncthreads();
 }
 

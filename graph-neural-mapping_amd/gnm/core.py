@@ -297,6 +297,11 @@ def _linear_wide(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
         _linear(x, Wv, w_kmajor, bias[h0:h0 + hw] if bias is not None else None, z[:, h0:h0 + hw], N, K, hw, pro, None)
 
 
+# the K = H = 64 Linear backward recomputes the Linear's output from its input instead of reading it
+# (gnm_linear_bwd_fused_rz); GNM_NO_RZ=1 keeps the form that reads the stored output (A/B and tests)
+RZ_BACKWARD = os.environ.get("GNM_NO_RZ", "0") != "1"
+
+
 class _LinSave:
     __slots__ = ("x_in", "pro", "z", "scale", "shift", "mean", "rstd", "K", "H", "Ng")
 
@@ -873,17 +878,30 @@ class GinInfoMaxFn(torch.autograd.Function):
                 if lo is not None and need_dA:
                     lo_part = torch.empty((lib.gnm_linear_bwd_grid(N), 2, K), dtype=torch.float64, device=dev)
                 with _timed("linbwd_K%d_H%d" % (K, Hk), N=N, K=K, H=Hk) as tm:
-                    rc = lib.gnm_linear_bwd_fused(
+                    lo_args = (lo.z.data_ptr() if lo_part is not None else None,
+                               lo.z.stride(0) if lo_part is not None else 0,
+                               lo.scale.data_ptr() if lo_part is not None else None,
+                               lo.shift.data_ptr() if lo_part is not None else None,
+                               lo.mean.data_ptr() if lo_part is not None else None,
+                               lo.rstd.data_ptr() if lo_part is not None else None, ptr(lo_part), st)
+                    rc = -2
+                    if RZ_BACKWARD and K == 64 and Hk == 64 and need_dA:
+                        # sv.z = Linear(sv.x_in) as gnm_linear_fwd left it: the pass recomputes it instead of reading it
+                        rc = lib.gnm_linear_bwd_fused_rz(
+                            G.data_ptr(), G.stride(0), P[wname + ".bias"].data_ptr(), sv.mean.data_ptr(),
+                            sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), sv.x_in.data_ptr(),
+                            sv.x_in.stride(0), ptr(sv.pro[0]) if sv.pro else None, ptr(sv.pro[1]) if sv.pro else None,
+                            1 if sv.pro else 0, W.data_ptr(), W.stride(0), ptr(dA), dA.stride(0),
+                            None if DEFER_WGRAD_REDUCE else dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(),
+                            N, K, Hk, *lo_args)
+                    if rc == -2:
+                      rc = lib.gnm_linear_bwd_fused(
                         G.data_ptr(), G.stride(0), sv.z.data_ptr(), sv.z.stride(0), sv.mean.data_ptr(),
                         sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), sv.x_in.data_ptr(),
                         sv.x_in.stride(0), ptr(sv.pro[0]) if sv.pro else None, ptr(sv.pro[1]) if sv.pro else None,
                         1 if sv.pro else 0, W.data_ptr(), W.stride(0), ptr(dA), dA.stride(0) if need_dA else 0,
                         None if DEFER_WGRAD_REDUCE else dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), N, K, Hk,
-                        lo.z.data_ptr() if lo_part is not None else None, lo.z.stride(0) if lo_part is not None else 0,
-                        lo.scale.data_ptr() if lo_part is not None else None,
-                        lo.shift.data_ptr() if lo_part is not None else None,
-                        lo.mean.data_ptr() if lo_part is not None else None,
-                        lo.rstd.data_ptr() if lo_part is not None else None, ptr(lo_part), st)
+                        *lo_args)
                     if rc != 0:
                         tm.cancel()
                 if rc == 0 and DEFER_WGRAD_REDUCE:

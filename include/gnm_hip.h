@@ -193,6 +193,17 @@ int gnm_linear_bwd_fused(const float* G, int ldg, const float* Z, int ldz, const
                          float* dA, int lda, float* dW, int lddw, float* db, float* workspace, int N, int K, int H,
                          const float* sZ, int ldsz, const float* s_scale, const float* s_shift, const float* s_mean,
                          const float* s_rstd, double* s_partial, void* stream);
+/* The same pass for a Linear whose stored output the caller does not hand over: Z = f(X) W^T + bias (what
+ * gnm_linear_fwd wrote, mlp.py:43,49) is recomputed in the kernel instead of being read -- three [N,64] streams instead
+ * of four.  K = H = 64 and dA wanted; sZ either NULL or == X with (s_scale, s_shift) == (pro_scale, pro_shift) and
+ * pro_relu (the two Linears of a 2-layer MLP).  Anything else: GNM_ERR_UNSUPPORTED, nothing launched -- call
+ * gnm_linear_bwd_fused with Z.  Workspace, partial rows and the dW = NULL deferral as for gnm_linear_bwd_fused. */
+int gnm_linear_bwd_fused_rz(const float* G, int ldg, const float* bias, const float* mean, const float* rstd,
+                            const float* cA, const float* m1, const float* m2, const float* X, int ldx,
+                            const float* pro_scale, const float* pro_shift, int pro_relu, const float* W, int ldw,
+                            float* dA, int lda, float* dW, int lddw, float* db, float* workspace, int N, int K, int H,
+                            const float* sZ, int ldsz, const float* s_scale, const float* s_shift, const float* s_mean,
+                            const float* s_rstd, double* s_partial, void* stream);
 /* dW = NULL defers the reduction of the per-workgroup dW / db partials: they stay in `workspace` (keep it alive and
  * unshared) until ONE gnm_reduce_partials_multi call reduces up to 32 such workspaces of the same N, e.g. at the end
  * of a backward pass (nothing in the backward reads a weight gradient).  HOST arrays of njobs entries. */

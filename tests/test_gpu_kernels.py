@@ -4,12 +4,17 @@ size-independent properties at BASELINE.json's full sizes (n = 400, E = 47,600, 
 
 Tolerance: 1e-5 relative (max-norm) for every fp32 kernel, written at each check."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 import torch
 
 from helpers import assert_close
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -462,6 +467,82 @@ def test_linear_backward_fused(N, K, H, pro, want_dx):
             assert_close(st2[0], Gref2.sum(0), rtol=TOL, what="sum g (sZ = X)", floor=fl2)
             assert_close(st2[1], (Gref2 * xh2).sum(0), rtol=TOL, what="sum g*xhat (sZ = X)", floor=fl2)
             assert_close(dW3.cpu().numpy(), dZ.T @ Xe, rtol=TOL, what="dW (sZ = X)")
+
+
+@pytest.mark.parametrize("wg16", ["1", "0"])
+def test_linear_backward_recomputing_its_output(wg16):
+    """gnm_linear_bwd_fused_rz (K = H = 64): the pass that recomputes Z = f(X) W^T + b instead of reading it, against
+    fp64 and against gnm_linear_bwd_fused fed the Z that gnm_linear_fwd wrote.  samez: the second Linear of an MLP
+    (prologue = the lower BatchNorm + ReLU; its mask and backward sums come out of the same pass).  wg16: the weight
+    gradient on the bf16 pipe / with the fp32 instruction (a process-wide knob: run in a child process)."""
+    code = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from gnm import core
+from gnm._cabi import check, lib
+DEV = torch.device("cuda:0")
+K = H = 64
+for N, samez in [(n, z) for n in (1, 31, 4096 + 77, 40000 + 5) for z in (0, 1)]:
+  rng = np.random.default_rng(N + samez)
+  t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(DEV)
+  X = (rng.standard_normal((N, K)) * 1.5 + 0.3).astype(np.float32)
+  W = (rng.standard_normal((H, K)) / 8).astype(np.float32)
+  b = rng.standard_normal(H).astype(np.float32)
+  G = rng.standard_normal((N, H)).astype(np.float32)
+  sc, sh = rng.uniform(0.5, 1.5, K).astype(np.float32), rng.standard_normal(K).astype(np.float32)
+  lmu, lrs = rng.standard_normal(K).astype(np.float32), rng.uniform(0.5, 1.5, K).astype(np.float32)
+  mean, rstd, cA, m1, m2 = (rng.uniform(0.5, 1.5, H).astype(np.float32) for _ in range(5))
+  Xd, Wd, bd, Gd, scd, shd, lmud, lrsd = map(t, (X, W, b, G, sc, sh, lmu, lrs))
+  vec = [t(v) for v in (mean, rstd, cA, m1, m2)]
+  st = torch.cuda.current_stream().cuda_stream
+  Z = torch.empty(N, H, device=DEV)
+  core._linear(Xd, Wd, 0, bd, Z, N, K, H, (scd, shd) if samez else None, None)
+  grid = lib.gnm_linear_bwd_grid(N)
+  out = []
+  for rz in (True, False):
+      dA = torch.full((N, K), float("nan"), device=DEV)
+      dW = torch.full((H, K), float("nan"), device=DEV)
+      db = torch.full((H,), float("nan"), device=DEV)
+      ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, H, K)), device=DEV)
+      part = torch.full((grid, 2, K), float("nan"), dtype=torch.float64, device=DEV)
+      lo = (Xd.data_ptr(), K, scd.data_ptr(), shd.data_ptr(), lmud.data_ptr(), lrsd.data_ptr(), part.data_ptr()) if samez \
+          else (None, 0, None, None, None, None, None)
+      pro = (scd.data_ptr(), shd.data_ptr(), 1) if samez else (None, None, 0)
+      tail = (Xd.data_ptr(), K) + pro + (Wd.data_ptr(), K, dA.data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(),
+                                        N, K, H) + lo + (st,)
+      if rz:
+          check(lib.gnm_linear_bwd_fused_rz(Gd.data_ptr(), H, bd.data_ptr(), *[v.data_ptr() for v in vec], *tail), "rz")
+      else:
+          check(lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Z.data_ptr(), H, *[v.data_ptr() for v in vec], *tail), "fused")
+      torch.cuda.synchronize()
+      out.append([a.cpu().numpy() for a in (dA, dW, db, part.sum(0))])
+  # fp64 reference
+  X64 = X.astype(np.float64)
+  F64 = np.maximum(X64 * sc + sh, 0) if samez else X64
+  Z64 = F64 @ W.astype(np.float64).T + b
+  dZ = cA * (G - m1 - (Z64 - mean) * rstd * m2)
+  dA_ref = dZ @ W.astype(np.float64)
+  if samez:
+      dA_ref = dA_ref * ((X * sc + sh) > 0)
+  def close(got, ref, tol, what):
+      err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30)          # max-norm relative, as everywhere in this file
+      assert err < tol, (what, err)
+  for name, (dA, dW, db, ps) in zip(("rz", "stored Z"), out):
+      close(dA, dA_ref, 1e-5, name + " dA")
+      close(dW, dZ.T @ F64, 1e-5, name + " dW")
+      close(db, dZ.sum(0), 1e-5, name + " db")
+      if samez:
+          close(ps[0], dA_ref.sum(0), 1e-5, name + " sum g")
+          close(ps[1], (dA_ref * ((X64 - lmu) * lrs)).sum(0), 1e-5, name + " sum g xhat")
+  # the two passes see the same Z (the recomputation repeats gnm_lin_split_kernel's instruction sequence)
+  dmax = np.abs(out[0][0] - out[1][0]).max()
+  print("N", N, "samez", samez, "max |dA(rz) - dA(stored Z)| =", dmax)
+  assert dmax <= 1e-6 * np.abs(out[1][0]).max()
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "graph-neural-mapping_amd"))
+    env = dict(os.environ, GNM_LINBWD_WG16=wg16, GNM_LINBWD_RZ_STATS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_linear_backward_deferred_weight_reduction():

@@ -24,7 +24,7 @@ import torch
 from gnm import core
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--kernel", default="fwd", choices=["fwd", "bwd", "bwd_first"])
+ap.add_argument("--kernel", default="fwd", choices=["fwd", "bwd", "bwd_first", "rz", "rz_first"])
 args = ap.parse_args()
 lib = core.lib
 lib.gnm_debug_set_lin_stamps.argtypes = [C.c_void_p]
@@ -42,6 +42,7 @@ lmean, lrstd = torch.randn(K, **f32) * 0.1, torch.rand(K, **f32) + 0.5
 dW, db = torch.empty(H, K, **f32), torch.empty(H, **f32)
 st = torch.cuda.current_stream().cuda_stream
 fwd = args.kernel == "fwd"
+rz = args.kernel.startswith("rz")
 grid = lib.gnm_linear_grid(N) if fwd else lib.gnm_linear_bwd_grid(N)
 stats = torch.empty(grid, 2, H, dtype=torch.float64, device=dev)
 ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, H, K)), **f32)
@@ -53,7 +54,16 @@ def run():
         core.check(lib.gnm_linear_fwd(x.data_ptr(), K, W.data_ptr(), K, 0, b.data_ptr(), out.data_ptr(), H, N, K, H,
                                       sc.data_ptr(), sh.data_ptr(), 1, stats.data_ptr(), st), "lin")
         return
-    second = args.kernel == "bwd"
+    second = args.kernel in ("bwd", "rz")
+    if rz:
+        core.check(lib.gnm_linear_bwd_fused_rz(
+            g.data_ptr(), H, b.data_ptr(), mean.data_ptr(), rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+            (zlo if second else x).data_ptr(), K, sc.data_ptr() if second else None, sh.data_ptr() if second else None,
+            1 if second else 0, W.data_ptr(), K, dA.data_ptr(), K, dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, K, H,
+            zlo.data_ptr() if second else None, K if second else 0, sc.data_ptr() if second else None,
+            sh.data_ptr() if second else None, lmean.data_ptr() if second else None, lrstd.data_ptr() if second else None,
+            lp.data_ptr() if second else None, st), "rz")
+        return
     core.check(lib.gnm_linear_bwd_fused(
         g.data_ptr(), H, z.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(),
         (zlo if second else x).data_ptr(), K, sc.data_ptr() if second else None, sh.data_ptr() if second else None,
@@ -65,37 +75,42 @@ def run():
 
 for _ in range(5):
     run()
-stamps = torch.zeros(grid * 4 * 64, dtype=torch.int64, device=dev)
+WPB = 8 if rz else 4                                              # waves per workgroup
+nwg = (grid + 1) // 2 if rz else grid
+stamps = torch.zeros(nwg * WPB * 64, dtype=torch.int64, device=dev)
 lib.gnm_debug_set_lin_stamps(stamps.data_ptr())
 run(); torch.cuda.synchronize(); stamps.zero_()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); run(); e1.record(); torch.cuda.synchronize()
 lib.gnm_debug_set_lin_stamps(None)
 ms = e0.elapsed_time(e1)
-s = stamps.cpu().numpy().reshape(grid, 4, 64).astype(np.float64)
-per = 4 if fwd else 5
+s = stamps.cpu().numpy().reshape(nwg, WPB, 64).astype(np.float64)
+per = 4 if fwd else (6 if rz else 5)
 names = (["wait for X + stage + read A", "64 MFMAs (+ B from LDS)", "epilogue + stores"] if fwd else
+         ["wait for X rows + split + Z MFMAs", "wait for G + dZ + image + issue X column loads", "dgrad (image rows, split, MFMAs)",
+          "mask / statistics / staging + dX stores", "next tile's requests + wgrad (split, MFMAs)"] if rz else
          ["wait for G, Z + dZ tile to LDS + issue X loads", "dgrad: 64 MFMAs", "wgrad: wait for X + 64 MFMAs",
           "mask / statistics / dX stores"])
-ntile = (s[:, :, 2:2 + per * 12:per] > 0).sum(2)                  # tiles stamped per wave (first 12 at most)
-life = s[:, :, 62] - s[:, :, 0]
+NT = 10 if rz else 12
+ntile = (s[:, :, 2:2 + per * NT:per] > 0).sum(2)                  # tiles stamped per wave (first NT at most)
+life = np.where(s[:, :, 62] > s[:, :, 0], s[:, :, 62] - s[:, :, 0], np.nan)
 print("%s: launch %.1f us (stamped build), grid %d, tiles per wave %d..%d" % (args.kernel, ms * 1e3, grid, ntile.min(), ntile.max()))
 print("  shares of a wave's lifetime (entry -> tile loop left), mean over waves:")
-print("    weight staging + barrier                        %5.1f %%" % (100 * ((s[:, :, 1] - s[:, :, 0]) / life).mean()))
+print("    weight staging + barrier                        %5.1f %%" % (100 * np.nanmean((s[:, :, 1] - s[:, :, 0]) / life)))
 tot = np.zeros((len(names) + 1,) + life.shape)
-for t in range(12):
+for t in range(NT):
     ok = s[:, :, 2 + per * t] > 0
     for k in range(len(names)):
         tot[k] += np.where(ok, s[:, :, 3 + per * t + k] - s[:, :, 2 + per * t + k], 0.0)
-    if t + 1 < 12:
+    if t + 1 < NT:
         ok2 = ok & (s[:, :, 2 + per * (t + 1)] > 0)
         tot[-1] += np.where(ok2, s[:, :, 2 + per * (t + 1)] - s[:, :, 2 + per * t + len(names)], 0.0)
 for k, nm in enumerate(names):
     print("    %-47s %5.1f %%" % (nm, 100 * (tot[k] / life).mean()))
 print("    %-47s %5.1f %%" % ("between tiles", 100 * (tot[-1] / life).mean()))
 last = s[:, :, 62].max(1, keepdims=True)
-print("    idle until the block's last wave leaves the loop  %5.1f %% (in addition)" % (100 * ((last - s[:, :, 62]) / life).mean()))
+print("    idle until the block's last wave leaves the loop  %5.1f %% (in addition)" % (100 * np.nanmean((last - s[:, :, 62]) / life)))
 if not fwd:
-    print("    loop left -> kernel exit (dW / statistics combine)  %5.1f %% (in addition)" % (100 * ((s[:, :, 63] - s[:, :, 62]) / life).mean()))
+    print("    loop left -> kernel exit (dW / statistics combine)  %5.1f %% (in addition)" % (100 * np.nanmean((s[:, :, 63] - s[:, :, 62]) / life)))
 blk = s[:, :, 62].max(1) - s[:, :, 0].min(1)
 print("  block lifetime spread (ticks): min %.0f median %.0f max %.0f" % (blk.min(), np.median(blk), blk.max()))
