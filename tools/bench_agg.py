@@ -114,25 +114,6 @@ def main():
                                     batch.n_max, x.data_ptr(), F, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, 0, None, 0,
                                     None, st), "gnm_aggm")
             return
-        if mode in ("tplain", "tfused"):          # the transposed-role kernel (csrc/aggt.hip), same arguments
-            _p, _i = C.c_void_p, C.c_int
-            lib.gnm_aggt.restype = _i
-            lib.gnm_aggt.argtypes = _cabi.SIGNATURES["gnm_aggm"][1]
-            lib.gnm_aggt_fwd_bnrelu.restype = _i
-            lib.gnm_aggt_fwd_bnrelu.argtypes = _cabi.SIGNATURES["gnm_aggm_fwd_bnrelu"][1]
-            if mode == "tplain":
-                core.check(lib.gnm_aggt(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(),
-                                        batch.col_off.data_ptr(), a.bits.buf.data_ptr(), batch.bits_off.data_ptr(),
-                                        a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(), batch.node_off.data_ptr(), B,
-                                        batch.n_max, x.data_ptr(), F, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, 0, None, 0,
-                                        None, st), "gnm_aggt")
-            else:
-                core.check(lib.gnm_aggt_fwd_bnrelu(
-                    a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
-                    a.bits.buf.data_ptr(), batch.bits_off.data_ptr(), batch.node_off.data_ptr(), B, batch.n_max,
-                    x.data_ptr(), F, sc.data_ptr(), sh.data_ptr(), h.data_ptr() if args.keep_hidden else None, F, gf.data_ptr(),
-                    F, 0, y.data_ptr(), F, F, eps.data_ptr(), 0, 0, st), "gnm_aggt_fwd_bnrelu")
-            return
         if mode == "mfused":
             core.check(lib.gnm_aggm_fwd_bnrelu(
                 a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.rp_off.data_ptr(), batch.col_off.data_ptr(),
