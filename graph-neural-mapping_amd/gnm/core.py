@@ -302,6 +302,23 @@ def _linear_wide(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
 RZ_BACKWARD = os.environ.get("GNM_NO_RZ", "0") != "1"
 
 
+# the three [B, L*H]-sized products of the Infomax tail on the hand-written kernel (csrc/sgemm.hip); GNM_NO_SGEMM=1
+# keeps torch.mm (hipBLASLt) for A/B timing
+SMALL_GEMM = os.environ.get("GNM_NO_SGEMM", "0") != "1"
+
+
+def _small_gemm(A, a_cols, B, b_cols, out, M, N, K):
+    """out[M,N] = A' B' (csrc/sgemm.hip: gnm_small_gemm); False when the kernel declines and the caller uses torch."""
+    if not SMALL_GEMM or A.stride(1) != 1 or B.stride(1) != 1 or out.stride(1) != 1:
+        return False
+    rc = lib.gnm_small_gemm(A.data_ptr(), A.stride(0), int(a_cols), B.data_ptr(), B.stride(0), int(b_cols), out.data_ptr(),
+                            out.stride(0), M, N, K, _stream())
+    if rc == -2:
+        return False
+    check(rc, "gnm_small_gemm")
+    return True
+
+
 class _LinSave:
     __slots__ = ("x_in", "pro", "z", "scale", "shift", "mean", "rstd", "K", "H", "Ng")
 
@@ -646,7 +663,10 @@ class GinInfoMaxFn(torch.autograd.Function):
                 raise RuntimeError("Discriminator expands each graph summary N//B times (discriminator.py:24): "
                                    "all graphs of a batch must have the same number of nodes")
             Wd = P["disc.f_k.weight"][0]
-            U = c @ Wd.t()                                                    # U[g] = W c_g
+            LH = Wd.shape[1]
+            U = torch.empty((B, Wd.shape[0]), dtype=torch.float32, device=X.device)
+            if not _small_gemm(c, 0, Wd, 0, U, B, Wd.shape[0], LH):
+                U = c @ Wd.t()                                                # U[g] = W c_g
             if torch.is_tensor(perm) and perm.is_cuda:      # graph-capture safe: already on the device
                 perm_rows = perm.to(torch.int32)
             else:
@@ -748,15 +768,21 @@ class GinInfoMaxFn(torch.autograd.Function):
             if hold is not None:
                 hold.k = hold.dD_ptr = None
             Wd = P["disc.f_k.weight"][0]
-            # (the three [B, L*H]-sized products of the tail stay library GEMMs: a hand-written fp32-MFMA kernel was
-            #  tried in round 3 and measured 48 us per product against 9-12 us -- 25-80 workgroups do not fill the chip)
+            # (the three [B, L*H]-sized products of the tail: csrc/sgemm.hip -- one workgroup per 32 x 32 output tile, the
+            #  contraction split over its four waves, split-precision bf16 products.  A first hand-written version on the
+            #  fp32 matrix instruction measured 48 us per product against hipBLASLt's 9-12 us.)
+            Bc = dU.shape[0]
+            dWd = sink["disc.f_k.weight"][0] if sink is not None else torch.empty_like(Wd)
+            if not _small_gemm(dU, 1, c, 1, dWd, dU.shape[1], c.shape[1], Bc):          # dWd = dU^T c
+                torch.mm(dU.t(), c, out=dWd)
             if sink is not None:
-                torch.mm(dU.t(), c, out=sink["disc.f_k.weight"][0])
                 torch.sum(dsum, 0, keepdim=True, out=sink["disc.f_k.bias"])
             else:
-                grads["disc.f_k.weight"] = (dU.t() @ c).unsqueeze(0)
+                grads["disc.f_k.weight"] = dWd.unsqueeze(0)
                 grads["disc.f_k.bias"] = dsum.sum().reshape(1)
-            T = dU @ Wd                                                       # d loss / d sigmoid(g_f)
+            T = torch.empty((Bc, Wd.shape[1]), **f32)
+            if not _small_gemm(dU, 0, Wd, 1, T, Bc, Wd.shape[1], Wd.shape[0]):            # d loss / d sigmoid(g_f) = dU Wd
+                T = dU @ Wd
             dsc1 = dD                                                         # first N entries = d sc_1
 
         # ---- classifier head: d g_f (classifier + sigmoid paths) and the classifier gradients ------------

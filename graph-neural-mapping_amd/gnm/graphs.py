@@ -11,9 +11,34 @@ gradient all-reduce stays outside the graph.
 Everything shape-like is frozen at capture: B, N (equal-size graphs), model options.
 """
 import numpy as np
+import contextlib
+import gc
+
 import torch
 
 from .arena import PackedStaticBatch, StaticBatch
+
+
+
+@contextlib.contextmanager
+def _capture(graph, pool=None):
+    """torch.cuda.graph(...) with Python's cyclic garbage collector held off for the duration of the capture.
+    torch collects once on entry, but a collection can also START inside the captured region (allocation counts cross a
+    threshold -- in the autograd thread as well) and free whatever cyclic garbage the warm-up passes left: a pinned
+    staging tensor or an event released there is a synchronising HIP call on a capturing stream and aborts the process
+    (seen once in test_run_to_run_determinism: "Fatal Python error: Aborted ... Garbage-collecting ... _backward")."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        kw = {"capture_error_mode": "thread_local"}
+        if pool is not None:
+            kw["pool"] = pool
+        with torch.cuda.graph(graph, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 class CapturedTrainStep:
@@ -48,7 +73,7 @@ class CapturedTrainStep:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: other threads of the process (e.g. RCCL's watchdog) keep issuing HIP calls
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with _capture(self.graph):
             self.loss = self._step()
         with torch.no_grad():
             for t, s0 in zip(keep, snapshot):
@@ -142,7 +167,7 @@ class CapturedEval:
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+        with _capture(self.graph):
             self.c_logit, self.d_logit, self.g_f = self._forward()
         torch.cuda.synchronize(dev)
         self._arena_ptrs = self._arena_buffers()
@@ -249,12 +274,12 @@ class CapturedTrain:
             torch.cuda.current_stream(dev).wait_stream(s)
             torch.cuda.synchronize(dev)
             self.fwd_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.fwd_graph, capture_error_mode="thread_local"):
+            with _capture(self.fwd_graph):
                 self.c_logit, self.d_logit, _ = self._forward()
             self.dC = torch.zeros_like(self.c_logit)
             self.dD = torch.zeros_like(self.d_logit)
             self.bwd_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.bwd_graph, pool=self.fwd_graph.pool(), capture_error_mode="thread_local"):
+            with _capture(self.bwd_graph, pool=self.fwd_graph.pool()):
                 torch.autograd.grad((self.c_logit, self.d_logit), self._req, (self.dC, self.dD), allow_unused=True)
         finally:
             model._spec.grad_sink = sink

@@ -210,6 +210,14 @@ int gnm_linear_bwd_fused_rz(const float* G, int ldg, const float* bias, const fl
 int gnm_reduce_partials_multi(const float* const* workspaces_host, float* const* dW_host, const int* lddw_host,
                               float* const* db_host, const int* Hs_host, const int* Ks_host, int njobs, int N,
                               void* stream);
+
+/* The [B, L*H]-sized matrix products of the Infomax tail (discriminator.py:30-31 through nn.Bilinear, restructured as
+ * U = sigmoid(g_f) Wd^T with backward dWd = dU^T sigmoid(g_f), T = dU Wd): C[M,N] = A' B', fp32 in and out, fp32-accurate
+ * (split-precision bf16 products), fixed summation order.  A' = A ([M][K], a_cols = 0) or A^T (A given as [K][M],
+ * a_cols = 1); B' = B^T (B given as [N][K], b_cols = 0) or B ([K][N], b_cols = 1).  GNM_ERR_UNSUPPORTED (nothing
+ * launched) when an operand exceeds a 32-bit byte offset. */
+int gnm_small_gemm(const float* A, int lda, int a_cols, const float* B, int ldb, int b_cols, float* C, int ldc, int M, int N,
+                   int K, void* stream);
 /* sZ (optional): dA is the gradient arriving at relu(bn_lo(sZ)), the BatchNorm+ReLU feeding this Linear
  * (mlp.py:48).  Then dA is written already multiplied by that ReLU mask and s_partial receives
  * [gnm_linear_bwd_grid(N)][2][K] doubles (sum g, sum g*xhat) for gnm_bn_bwd_finalize -- i.e. the call also

@@ -1141,3 +1141,36 @@ def test_aggregation_of_graphs_too_large_for_lds(average, learn_eps, F):
         want = float((dp64 * x64).sum())
         assert abs(float(part[:cnt].sum().item()) - want) <= 1e-6 * float(np.abs(dp64 * x64).sum())
 
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 320, 320), (37, 64, 96), (1, 32, 32), (320, 320, 1000), (33, 40, 20), (64, 640, 640)])
+def test_small_gemm_all_operand_forms(M, N, K):
+    """gnm_small_gemm (csrc/sgemm.hip), the tail's three products: every operand form (row-major / column-major A and
+    B), sizes that are not multiples of the 32 x 32 tile or of the 16-wide step, an operand that is not 16-byte aligned
+    (a parameter inside the flat buffer), element by element below 1e-6 x sum_k |a||b| against fp64, and bitwise
+    reproducible."""
+    from gnm._cabi import check, lib
+    rng = np.random.default_rng(M + 7 * N + 13 * K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64)
+    bound = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64) + 1e-30
+    for a_cols in (0, 1):
+        for b_cols in (0, 1):
+            for off in (0, 3):
+                flat_a = torch.zeros(off + M * K, device=DEV)
+                Ad = flat_a[off:].view((K, M) if a_cols else (M, K))
+                Ad.copy_(torch.from_numpy(np.ascontiguousarray(A.T if a_cols else A)))
+                flat_b = torch.zeros(off + K * N, device=DEV)
+                Bd = flat_b[off:].view((K, N) if b_cols else (N, K))
+                Bd.copy_(torch.from_numpy(np.ascontiguousarray(Bm if b_cols else Bm.T)))
+                outs = []
+                for _ in range(2):
+                    C_ = torch.full((M, N + 5), float("nan"), device=DEV)
+                    check(lib.gnm_small_gemm(Ad.data_ptr(), Ad.stride(0), a_cols, Bd.data_ptr(), Bd.stride(0), b_cols,
+                                             C_.data_ptr(), N + 5, M, N, K, _stream()), "gnm_small_gemm")
+                    outs.append(C_.cpu().numpy())
+                assert np.isnan(outs[0][:, N:]).all()
+                err = np.abs(outs[0][:, :N] - ref) / bound
+                assert err.max() < 1e-6, (a_cols, b_cols, off, err.max())
+                assert np.array_equal(outs[0][:, :N], outs[1][:, :N])
