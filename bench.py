@@ -378,6 +378,18 @@ def main():
                       % (type(e).__name__, e), file=sys.stderr)
                 capture_notes["step+allreduce"] = "%s: %s" % (type(e).__name__, e)
                 captured_cc = None
+    if multi and world > 1:
+        # every rank must run the same launch mode (the trial below and the steps call collectives): a capture that
+        # failed on ONE rank demotes all of them
+        ok = torch.tensor([int(captured is not None), int(captured_cc is not None)], dtype=torch.int32,
+                          device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        ok = ok.cpu().tolist()
+        if not ok[0] and captured is not None:
+            captured = None
+            dp.fp.zero_grad()
+        if not ok[1]:
+            captured_cc = None
     perms = [np.random.permutation(B) for _ in range(nsteps)]     # graphcnn.py:199, one draw per forward
 
     # launch mode of a step: "graph+cc" (replay incl. the collective), "graph" (replay, collective launched behind
