@@ -2663,18 +2663,21 @@ __global__ void __launch_bounds__(kRzWaves * 64) gnm_linear_bwd_rz_kernel(const 
         GNM_RSTAMP(5 + 6 * min(tk, 9))
         // ---- dX out (SAMEZ: masked by the lower ReLU, and that BatchNorm's backward sums) ---------------------------
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
+            // (read once per column block: between the image stores below the compiler cannot keep an LDS value)
+            const float esc = SAMEZ ? psv[32 * c + i] : 1.f, esh = SAMEZ ? psv[64 + 32 * c + i] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
                 float gg = dacc[c][r];
                 if constexpr (SAMEZ) {
                     const float z = xv[r][c];
-                    if (!(z * psv[32 * c + i] + psv[64 + 32 * c + i] > 0.f)) gg = 0.f;
+                    if (!(z * esc + esh > 0.f)) gg = 0.f;
                     dacc[c][r] = gg;
                 }
                 Xs[lrow * XS + 32 * c + i] = gg;
             }
+        }
         if constexpr (SAMEZ) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -2772,7 +2775,7 @@ __global__ void __launch_bounds__(kRzWaves * 64) gnm_linear_bwd_rz_kernel(const 
         }
         if constexpr (SAMEZ) {
             __builtin_amdgcn_sched_barrier(0);
-            load_next_x(t_next);
+            load_next_x(t_next);      // (requested before the product it cost 24 spilled registers per tile: 122 us)
         }
         GNM_RSTAMP(7 + 6 * min(tk, 9))
         ++tk;
@@ -2974,7 +2977,7 @@ extern "C" int gnm_linear_bwd_fused_rz(const float* G, int ldg, const float* bia
     if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dA)) & 15) return GNM_ERR_UNSUPPORTED;
     if ((long long)32 * (ldg > ldx ? (ldg > lda ? ldg : lda) : (ldx > lda ? ldx : lda)) * 4 >= (1LL << 31)) return GNM_ERR_UNSUPPORTED;
     const bool samez = sZ != nullptr;
-    // the statistics form is correct and tested but measured BEHIND the kernel that reads Z (103.7 vs 98.6 us at the
+    // the statistics form is correct and tested but measured BEHIND the kernel that reads Z (101.9 vs 99.3 us at the
     // headline shape: its extra per-lane state lives in LDS); the plain form is ahead (87.9 vs 90.9 us).  GNM_LINBWD_RZ_STATS=1
     // enables it for A/B timing and for its test.
     static const bool rz_stats = gnm_env_int("GNM_LINBWD_RZ_STATS", 0) != 0;
