@@ -54,7 +54,7 @@ __device__ __forceinline__ void sg_fetch(const __amdgpu_buffer_rsrc_t rs, int ld
     if constexpr (MODE == 2) {
         // rows past K lie past the end of the operand: the descriptor's range check (which covers the scalar offset on
         // gfx950, see linear.hip gnm_tile_rsrc) returns zero for them -- one vector offset per fragment, no per-element selects
-        const unsigned voff = line < nlines ? (unsigned)((8 * h * ld + line) * 4) : 0xFFFFFFF0u;
+        const unsigned voff = line < nlines ? (unsigned)((8 * h * ld + line) * 4) : 0x80000000u;   // (past any operand; no wrap with the row offset)
 #pragma unroll
         for (int j = 0; j < 8; ++j)
             f[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (16 * s + j) * ld * 4, 0));

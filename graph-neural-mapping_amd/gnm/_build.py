@@ -9,7 +9,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 # GNM_HIP_LIB: load another build of the same C-ABI instead (A/B timing of kernel variants made by
 # tools/build_variant.py); unset in normal use
 LIB_PATH = os.environ.get("GNM_HIP_LIB") or os.path.join(LIB_DIR, "libgnm_hip.so")
-SOURCES = ["agg.hip", "aggm.hip", "maxpool.hip", "linear.hip", "norm.hip", "disc.hip", "head.hip", "tail.hip", "sgemm.hip", "evalfwd.hip", "host.cpp"]
+SOURCES = ["agg.hip", "aggm.hip", "maxpool.hip", "linear.hip", "norm.hip", "disc.hip", "head.hip", "tail.hip", "sgemm.hip", "evalfwd.hip", "evallayer.hip", "host.cpp"]
 
 
 def _hipcc():

@@ -69,6 +69,9 @@ SIGNATURES = {
     "gnm_eval_table_words": (_ll, [_i, _i]),
     "gnm_eval_encoder": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _ll, _i, _p,
                               _p, _i, _p, _i, _p, _p, _i, _p]),
+    "gnm_eval_layers_scratch_floats": (_ll, [_i, _i, _i, _i]),
+    "gnm_eval_layers": (_i, [_p, _p, _p, _p, _p, _i, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _ll, _i, _p,
+                             _p, _i, _p, _p, _i, _p]),
     "gnm_disc_score_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p]),
     "gnm_disc_score_fwd_unit": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p]),
     "gnm_disc_unit_scale": (_i, [_p, _i, _i, _p, _i, _p, _i, _p, _p, _p]),

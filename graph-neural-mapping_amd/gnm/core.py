@@ -522,20 +522,24 @@ _ptr_array = _hptr_array
 EVAL_FUSED = os.environ.get("GNM_NO_EVAL_FUSED") is None
 
 
-def eval_fused_ok(spec, batch, X, P):
-    """can this eval-mode forward run as the one-launch encoder (csrc/evalfwd.hip)?"""
+def eval_fused_ok(spec, batch, X, P, mode=True):
+    """can this eval-mode forward run as the one-launch encoder (csrc/evalfwd.hip; mode True) / as one launch per layer
+    with a workgroup per 32-row block (csrc/evallayer.hip; mode "layers")?"""
     if not EVAL_FUSED or spec.n_max or spec.sync_bn is not None or spec.keep_hidden:
         return False
-    if not getattr(batch, "has_bits", False) or batch.B < 1 or batch.n_max > int(lib.gnm_eval_max_nodes()):
+    layers = mode == "layers"
+    if not getattr(batch, "has_bits", False) or batch.B < 1 or batch.n_max > (416 if layers else int(lib.gnm_eval_max_nodes())):
         return False
     if spec.n_avg and spec.learn_eps and getattr(batch, "iso", False):
         return False            # the 0/0 row of an isolated node must stay confined to its row (see _dense)
     H = P["batch_norms.0.weight"].shape[0]
     C_ = P["linears_prediction.0.weight"].shape[0]
+    if layers:
+        return H in (32, 64, 128) and 1 <= spec.m <= 3 and spec.L <= 16 and X.shape[1] <= 128 and C_ <= 256 and X.is_cuda
     return H == 64 and 1 <= spec.m <= 3 and spec.L <= 16 and X.shape[1] <= 64 and C_ <= 64 and X.is_cuda
 
 
-def eval_forward_fused(spec, batch, perm, P, X, want_disc):
+def eval_forward_fused(spec, batch, perm, P, X, want_disc, mode=True):
     """GIN_InfoMaxReg.forward in eval() mode (graphcnn.py:194-251 with BatchNorm on its running statistics and dropout
     off) as ONE encoder launch (gnm_eval_encoder: layers + readout + classifier, a workgroup per graph) plus, for the
     Infomax scores, U = sigmoid(g_f) W^T and the score kernel.  No autograd graph: callers use it under no_grad only
@@ -574,11 +578,22 @@ def eval_forward_fused(spec, batch, perm, P, X, want_disc):
     table = cached[1]
     hidden_all = torch.empty((L, N, H), **f32)
     hidden = [hidden_all[l] for l in range(L)]
-    s0, s1 = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
     g_f = torch.empty((B, L * H), **f32)
     c = torch.empty_like(g_f) if want_disc else None
     c_logit = torch.empty((B, Cn), **f32)
-    with _stream_scope(dev):
+    if mode == "layers":
+        scratch = torch.empty(int(lib.gnm_eval_layers_scratch_floats(B, batch.n_max, H, L)), **f32)
+        with _stream_scope(dev):
+            check(lib.gnm_eval_layers(
+                a.bits.buf.data_ptr(), batch.bits_off.data_ptr(), batch.node_off.data_ptr(), a.rowptr.buf.data_ptr(),
+                batch.rp_off.data_ptr(), B, batch.n_max, X.data_ptr(), X.stride(0), X.shape[1], H, L, m, Cn,
+                int(spec.n_avg), int(not spec.learn_eps), int(spec.g_avg), BN_EPS, table.data_ptr(),
+                P["eps"].data_ptr() if spec.learn_eps else None, hidden_all.data_ptr(), hidden_all.stride(0), H,
+                scratch.data_ptr(), g_f.data_ptr(), g_f.stride(0), ptr(c), c_logit.data_ptr(), c_logit.stride(0),
+                _stream()), "gnm_eval_layers")
+    else:
+      s0, s1 = torch.empty((N, H), **f32), torch.empty((N, H), **f32)
+      with _stream_scope(dev):
         check(lib.gnm_eval_encoder(
             a.bits.buf.data_ptr(), batch.bits_off.data_ptr(), batch.node_off.data_ptr(), a.rowptr.buf.data_ptr(),
             batch.rp_off.data_ptr(), B, batch.n_max, X.data_ptr(), X.stride(0), X.shape[1], H, L, m, Cn,
@@ -586,12 +601,16 @@ def eval_forward_fused(spec, batch, perm, P, X, want_disc):
             P["eps"].data_ptr() if spec.learn_eps else None, hidden_all.data_ptr(), hidden_all.stride(0), H,
             s0.data_ptr(), s1.data_ptr(), H, g_f.data_ptr(), g_f.stride(0), ptr(c), c_logit.data_ptr(),
             c_logit.stride(0), _stream()), "gnm_eval_encoder")
+    with _stream_scope(dev):
         d_logit = torch.zeros((0, 1), **f32)
         if want_disc:
             if not batch.equal_n:
                 raise RuntimeError("Discriminator expands each graph summary N//B times (discriminator.py:24): "
                                    "all graphs of a batch must have the same number of nodes")
-            U = c @ P["disc.f_k.weight"][0].t()                               # U[g] = W c_g
+            Wd = P["disc.f_k.weight"][0]
+            U = torch.empty((B, Wd.shape[0]), **f32)
+            if not _small_gemm(c, 0, Wd, 0, U, B, Wd.shape[0], Wd.shape[1]):
+                U = c @ Wd.t()                                                # U[g] = W c_g
             if torch.is_tensor(perm) and perm.is_cuda:
                 perm_rows = perm.to(torch.int32)
             else:

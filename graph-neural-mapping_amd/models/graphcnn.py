@@ -57,7 +57,7 @@ class _LazyEvalGrad(torch.autograd.Function):
             X, P0 = batch.arena.features_and_agg0(batch, m._spec.n_avg, not m._spec.learn_eps)
             sink, m._spec.grad_sink = m._spec.grad_sink, None          # plain autograd gradients here
             try:
-                c, d, _ = m._run(batch, X, ctx.perm, want_disc=True, P0=P0)
+                c, d, _ = m._run(batch, X, ctx.perm, want_disc=True, P0=P0, allow_fused=False)
                 outs, gouts = [], []
                 for o, g in ((c, dC), (d, dD)):
                     if g is not None:
@@ -69,6 +69,36 @@ class _LazyEvalGrad(torch.autograd.Function):
                 m._spec.grad_sink = sink
         it = iter(grads)
         return (None, None, None, None, None) + tuple(next(it) if t.requires_grad else None for t in tensors)
+
+
+class _LazyEvalGradBatch(torch.autograd.Function):
+    """Outputs of an eval-mode forward that ran on the evaluation encoder (no autograd graph), attached to the
+    parameters like _LazyEvalGrad: backward() runs the differentiable forward on the same batch and differentiates that."""
+
+    @staticmethod
+    def forward(ctx, model, batch, X, P0, perm, c_logit, d_logit, *params):
+        ctx.model, ctx.batch, ctx.X, ctx.P0, ctx.perm = model, batch, X, P0, perm
+        return c_logit.view_as(c_logit), d_logit.view_as(d_logit)
+
+    @staticmethod
+    def backward(ctx, dC, dD):
+        m = ctx.model
+        names, tensors, _ = m._param_lists()
+        with torch.enable_grad():
+            sink, m._spec.grad_sink = m._spec.grad_sink, None          # plain autograd gradients here
+            try:
+                c, d, _ = m._run(ctx.batch, ctx.X, ctx.perm, want_disc=True, P0=ctx.P0, allow_fused=False)
+                outs, gouts = [], []
+                for o, g in ((c, dC), (d, dD)):
+                    if g is not None and o.requires_grad:
+                        outs.append(o)
+                        gouts.append(g)
+                req = [t for t in tensors if t.requires_grad]
+                grads = torch.autograd.grad(outs, req, gouts, allow_unused=True) if outs else [None] * len(req)
+            finally:
+                m._spec.grad_sink = sink
+        it = iter(grads)
+        return (None,) * 7 + tuple(next(it) if t.requires_grad else None for t in tensors)
 
 
 class _TrainReplayFn(torch.autograd.Function):
@@ -129,7 +159,10 @@ class GIN_InfoMaxReg(nn.Module):
         # at one 400-node graph per forward it is SLOWER than the replayed layer-by-layer kernels (0.245 vs 0.188 ms per
         # graph, gpurun_out/r03i_time_eval.log) -- one CU runs a graph's whole chain (MFMA floor ~57 us + 50 barriers)
         # where the ~110 replayed launches (~1.4 us apiece) each spread over several CUs.  DESIGN.md section 6.
-        self.eval_fused = False
+        # eval_fused = "layers": one launch per LAYER with a workgroup per 32-row block of every graph
+        # (csrc/evallayer.hip): 13 CUs work on a 400-node graph, ~10 launches per forward.  0.136 ms per graph -- the
+        # default.  False: the training kernels in eval mode.
+        self.eval_fused = "layers"
 
     @staticmethod
     def _check_kernel_limits(num_layers, input_dim, hidden_dim):
@@ -171,15 +204,23 @@ class GIN_InfoMaxReg(nn.Module):
             pl = self._plist = (names, tensors, dict(self.named_buffers()))
         return pl
 
-    def _run(self, batch, X, perm, want_disc, P0=None, hand_over=True):
+    def _run(self, batch, X, perm, want_disc, P0=None, hand_over=True, allow_fused=True):
         names, tensors, buffers = self._param_lists()
-        if not self.training and self.eval_fused and not torch.is_grad_enabled() and not X.requires_grad:
-            # evaluation without autograd (the replayed eval forward; callers under torch.no_grad()): one encoder launch
-            # for all layers instead of ~20 launches per layer (csrc/evalfwd.hip)
+        if (allow_fused and not self.training and self.eval_fused and not X.requires_grad
+                and not (P0 is not None and P0.requires_grad)):
+            # evaluation (the replayed eval forward, callers under torch.no_grad(), and -- so that every eval-mode
+            # forward of a model gives the same bits -- callers in grad mode too): the evaluation encoder
+            # (csrc/evallayer.hip / csrc/evalfwd.hip) instead of ~20 training-kernel launches per layer.  It records
+            # no autograd graph; in grad mode the outputs are attached lazily (_LazyEvalGradBatch), as the reference's
+            # eval outputs carry one (main.py:54 detaches them).  Saliency (X.requires_grad) takes the path below.
             P = dict(zip(names, tensors))
             P.update(buffers)
-            if eval_fused_ok(self._spec, batch, X, P):
-                return eval_forward_fused(self._spec, batch, perm, P, X, want_disc)
+            if eval_fused_ok(self._spec, batch, X, P, self.eval_fused):
+                with torch.no_grad():
+                    c_logit, d_logit, g_f = eval_forward_fused(self._spec, batch, perm, P, X, want_disc, self.eval_fused)
+                if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+                    c_logit, d_logit = _LazyEvalGradBatch.apply(self, batch, X, P0, perm, c_logit, d_logit, *tensors)
+                return c_logit, d_logit, g_f
         hold = None
         if want_disc and self.training and DISC_UNIT and hand_over and torch.is_grad_enabled():
             # let the score kernel leave the backward's reductions for the reference's BCE loss (gnm/core.py DiscUnit);

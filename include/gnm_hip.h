@@ -270,6 +270,18 @@ int gnm_eval_encoder(const uint32_t* adj_bits, const int64_t* b_bits_off, const 
                      float* hidden, long long hidden_stride, int ldh, float* s0, float* s1, int lds, float* g_f, int ldgf,
                      float* c_sig, float* c_logit, int ldc, void* stream);
 
+/* The same eval-mode encoder + readout + classifier as L + 1 launches: one launch per GIN layer with a workgroup per
+ * 32-row block of every graph (13 CUs work on one 400-node graph), then the readout sums + classifier head
+ * (graphcnn.py:208-231, main.py:49-57).  Arguments as gnm_eval_encoder, with `scratch`
+ * (gnm_eval_layers_scratch_floats(B, n_max, H, L) floats) in place of its two [N, H] arrays.  H in {32, 64, 128},
+ * 1 <= m <= 3, F0 <= 128, C <= 256, n_max <= 416, every graph with a bit adjacency: GNM_ERR_UNSUPPORTED otherwise. */
+long long gnm_eval_layers_scratch_floats(int B, int n_max, int H, int L);
+int gnm_eval_layers(const uint32_t* adj_bits, const int64_t* b_bits_off, const int32_t* node_off, const int32_t* rowptr,
+                    const int64_t* b_rp_off, int B, int n_max, const float* X, int ldx, int F0, int H, int L, int m, int C,
+                    int average, int self_loop, int graph_avg, float bn_eps, const long long* table, const float* eps,
+                    float* hidden, long long hidden_stride, int ldh, float* scratch, float* g_f, int ldgf, float* c_sig,
+                    float* c_logit, int ldc, void* stream);
+
 /* ---- Infomax discriminator (discriminator.py:19-38, graphcnn.py:233-246) ------------
  * hptrs_host: HOST array of L device pointers to the per-layer [N,H] hidden states
  * (n_f is never concatenated).  A layer may instead be given as the pre-BatchNorm output Z_l of its last Linear

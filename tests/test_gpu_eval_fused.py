@@ -1,6 +1,7 @@
-"""The one-launch evaluation encoder (csrc/evalfwd.hip, gnm_eval_encoder): eval-mode forwards under torch.no_grad() --
-what the reference's per-graph evaluation loop issues (main.py:49-57, 71-82) -- against the layer-by-layer kernels,
-the fp64 oracle and the reference's golden vectors."""
+"""The evaluation encoders -- one launch per graph (csrc/evalfwd.hip, gnm_eval_encoder; model.eval_fused = True) and one
+launch per layer with a workgroup per 32-row block (csrc/evallayer.hip, gnm_eval_layers; model.eval_fused = "layers") --
+under torch.no_grad(), what the reference's per-graph evaluation loop issues (main.py:49-57, 71-82): against the
+layer-by-layer kernels, the fp64 oracle and the reference's golden vectors."""
 import numpy as np
 import pytest
 import torch
@@ -11,9 +12,11 @@ from test_gpu_model_parity import make_graphs, make_model, oracle_batch, oracle_
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+MODES = [True, "layers"]
+ENTRY = {True: "gnm_eval_encoder", "layers": "gnm_eval_layers"}
 
 
-def random_model(L, m, f0, C, learn_eps, gpool, npool, seed):
+def random_model(L, m, f0, C, learn_eps, gpool, npool, seed, mode=True):
     from models.graphcnn import GIN_InfoMaxReg
     dev = torch.device(DEV)
     torch.manual_seed(seed)
@@ -30,7 +33,7 @@ def random_model(L, m, f0, C, learn_eps, gpool, npool, seed):
                 prm.copy_(torch.rand(prm.shape, generator=g) + 0.5 if name.endswith("weight")
                           else torch.randn(prm.shape, generator=g) * 0.2)
         model.eps.copy_(torch.randn(L, generator=g) * 0.3)
-    model.eval_fused = True                # (off by default: see models/graphcnn.py)
+    model.eval_fused = mode                # (off by default: see models/graphcnn.py)
     return model.eval()
 
 
@@ -56,14 +59,15 @@ def count_calls(monkeypatch, name):
     (1, 2, 3, 2, True, "sum", "sum", [1, 1]),                   # single-node graphs
     (4, 2, 7, 2, True, "sum", "average", [200] * 66),          # more graphs than the replay cache takes: plain eager call
 ])
-def test_fused_eval_equals_the_layer_by_layer_path(L, m, f0, C, learn_eps, gpool, npool, sizes, monkeypatch):
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_eval_equals_the_layer_by_layer_path(L, m, f0, C, learn_eps, gpool, npool, sizes, mode, monkeypatch):
     rng = np.random.default_rng(L * 100 + m * 10 + f0)
     graphs = random_graphs(rng, sizes, 0.3, True, f0=f0)
     model = random_model(L, m, f0, C, learn_eps, gpool, npool, seed=L + m)
     model.eval_replay = False
-    calls = count_calls(monkeypatch, "gnm_eval_encoder")
+    calls = count_calls(monkeypatch, ENTRY[mode])
     outs = []
-    for fused in (True, False):
+    for fused in (mode, False):
         model.eval_fused = fused
         model._eval_cache = {}
         with torch.no_grad():
@@ -93,12 +97,13 @@ def test_fused_eval_equals_the_layer_by_layer_path(L, m, f0, C, learn_eps, gpool
         assert rel_err(a, b.astype(np.float64)) <= max(2e-5, 3 * (e_fused + e_layer)), what
 
 
-def test_fused_eval_vs_fp64_oracle_and_golden():
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_eval_vs_fp64_oracle_and_golden(mode):
     """true shape (B = 2, n = 400, H = 64, L = 5): the reference's own eval outputs and the fp64 oracle"""
     case = "true_s0_eps1_gsum_nsum"
     cfg, state, d = load_case(case)
     model = make_model(cfg, state).eval()
-    model.eval_fused = True
+    model.eval_fused = mode
     graphs = make_graphs(cfg, d)
     with torch.no_grad():
         np.random.seed(cfg["np_seed"])
@@ -113,11 +118,12 @@ def test_fused_eval_vs_fp64_oracle_and_golden():
     cal.check(d_logit.cpu().numpy(), d["eval_d_logit"], td, what="d_logit")
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", ["true_s0_eps0_gsum_naverage", "true_s0_eps1_gaverage_naverage", "true_s0_eps0_gaverage_nsum"])
-def test_fused_eval_other_true_shape_goldens(case):
+def test_fused_eval_other_true_shape_goldens(case, mode):
     cfg, state, d = load_case(case)
     model = make_model(cfg, state).eval()
-    model.eval_fused = True
+    model.eval_fused = mode
     graphs = make_graphs(cfg, d)
     with torch.no_grad():
         np.random.seed(cfg["np_seed"])
@@ -129,12 +135,13 @@ def test_fused_eval_other_true_shape_goldens(case):
     cal.check(d_logit.cpu().numpy(), d["eval_d_logit"], td, what="d_logit")
 
 
-def test_fused_eval_is_used_by_the_replayed_evaluation_and_repeatable(monkeypatch):
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_eval_is_used_by_the_replayed_evaluation_and_repeatable(mode, monkeypatch):
     """the reference's loop: model([g]) per graph in eval mode (main.py:49-57) -- captured once, replayed; every
     replay launches the encoder, results are bitwise repeatable and equal the un-replayed call"""
     rng = np.random.default_rng(1)
     graphs = random_graphs(rng, [400] * 6, 0.3, True, f0=7)
-    model = random_model(5, 2, 7, 2, True, "sum", "sum", seed=3)
+    model = random_model(5, 2, 7, 2, True, "sum", "sum", seed=3, mode=mode)
     with torch.no_grad():
         first = [model([g])[0].clone() for g in graphs]
         again = [model([g])[0].clone() for g in graphs]
@@ -163,3 +170,52 @@ def test_shapes_outside_the_encoder_fall_back(monkeypatch):
     with torch.no_grad():
         m64(random_graphs(rng, [40, 40], 0.3, True, f0=5))
     assert len(calls) >= 1             # (the replayed evaluation calls it in its warm-up passes and once under capture)
+
+
+@pytest.mark.parametrize("H,sizes,f0", [(32, [100, 100], 5), (128, [65] * 3, 40), (64, [416, 416], 7), (64, [1], 2)])
+def test_per_layer_eval_other_widths_and_sizes(H, sizes, f0):
+    """gnm_eval_layers beyond the one-launch encoder's shapes: hidden 32 / 128, 416-node graphs (13 full row blocks), a
+    single node -- against the layer-by-layer kernels"""
+    from models.graphcnn import GIN_InfoMaxReg
+    from helpers import rel_err
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(H + len(sizes))
+    torch.manual_seed(H)
+    model = GIN_InfoMaxReg(3, 2, f0, H, 3, 0.5, True, "sum", "sum", dev).to(dev).eval()
+    model.eval_replay = False
+    graphs = random_graphs(rng, sizes, 0.2, True, f0=f0)
+    outs = []
+    for mode in ("layers", False):
+        model.eval_fused = mode
+        with torch.no_grad():
+            np.random.seed(9)
+            c_logit, d_logit = model(graphs)
+            np.random.seed(9)
+            lat = model(graphs, latent=True)
+        outs.append((c_logit.cpu().numpy(), d_logit.cpu().numpy(), lat))
+    for a, b, what in zip(outs[0], outs[1], ("c_logit", "d_logit", "latent")):
+        assert a.shape == b.shape and np.isfinite(a).all()
+        assert rel_err(a, b.astype(np.float64)) <= 3e-5, (what, rel_err(a, b.astype(np.float64)))
+
+
+def test_backward_through_an_eval_mode_forward_on_the_encoder():
+    """the reference's eval outputs carry an autograd graph (main.py:54 detaches them).  On the evaluation encoder the
+    values come from csrc/evallayer.hip and the graph is attached lazily: a backward through them gives the gradients
+    of the differentiable (layer-by-layer) eval forward."""
+    rng = np.random.default_rng(11)
+    graphs = random_graphs(rng, [60, 60, 60], 0.3, True, f0=7)
+    grads = []
+    for mode in ("layers", False):
+        model = random_model(3, 2, 7, 2, True, "sum", "sum", seed=5, mode=mode)
+        model.eval_replay = False
+        model.zero_grad()
+        np.random.seed(2)
+        c_logit, d_logit = model(graphs)                       # grad mode, eval(): what main.py:49-57 does
+        assert c_logit.requires_grad and d_logit.requires_grad
+        (c_logit.square().sum() + 0.1 * d_logit.sum()).backward()
+        grads.append({n: p.grad.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 20
+    from helpers import rel_err
+    for name in grads[0]:
+        # (the upstream gradient 2 c_logit differs by the two forwards' rounding; everything else is the same backward)
+        assert rel_err(grads[0][name], grads[1][name].astype(np.float64)) < 1e-4, name

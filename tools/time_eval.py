@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU time per graph of the reference's evaluation pattern -- model([g]) per graph in eval mode (main.py:49-57; the
 reference does NOT wrap it in no_grad, the outputs are detached) -- with the one-launch encoder on / off and with the
-call under torch.no_grad():  python tools/time_eval.py"""
+call under torch.no_grad(); eval_fused = "layers": one launch per layer, a workgroup per 32-row block:  python tools/time_eval.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "graph-neural-mapping_amd"))
@@ -10,7 +10,7 @@ from gnm import synth
 from models.graphcnn import GIN_InfoMaxReg
 dev = torch.device("cuda:0")
 graphs = synth.make_pool("dense_fc", 64)
-for fused in (False, True):
+for fused in (False, True, "layers"):
     for nograd in (False, True):
         torch.manual_seed(0)
         model = GIN_InfoMaxReg(5, 2, 7, 64, 2, 0.5, True, "sum", "sum", dev).to(dev).eval()
