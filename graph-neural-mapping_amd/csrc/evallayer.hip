@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256) gnm_eval_layer_kernel(const ElArgs p) {
     __shared__ __attribute__((aligned(16))) float T1[32 * kElTS];
     __shared__ __attribute__((aligned(16))) float part[4][32][33];
     __shared__ __attribute__((aligned(16))) char lut[128];
-    __shared__ float aff[3][kElMaxH];             // bias, scale, shift of the current Linear + the BatchNorm behind it
+    __shared__ unsigned bitsw[8][256];            // word j of thread t's half row of the block's adjacency bits
+    __shared__ float aff[3][3][kElMaxH];          // per Linear of the MLP: bias, scale, shift (the BatchNorm behind it, folded)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,6 +88,40 @@ __global__ void __launch_bounds__(256) gnm_eval_layer_kernel(const ElArgs p) {
         v.y = ((tid & 4) ? one : 0u) | ((tid & 8) ? one << 16 : 0u);
         *reinterpret_cast<el_u32x2*>(lut + 8 * tid) = v;
     }
+    // ---- everything the MLP needs that does not depend on the tile, requested NOW: the parameter table -> the
+    //      pointers -> the vectors and this wave's first two W fragments per Linear are three dependent round trips to
+    //      memory per Linear; taken one Linear at a time behind the aggregation they were most of this kernel's 17 us
+    const int NCT = H >> 5, KSB = 4 / NCT;
+    const int ctB = wave % NCT, khB = wave / NCT;
+    const int ncolB = 32 * ctB + i;                               // output column of this lane = row of W
+    const float* Wk[3];
+    int ldwk[3];
+    float fbw[3][2][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        Wk[k] = nullptr; ldwk[k] = 0;
+        if (k < p.m) {
+            const long long* te = p.table + (size_t)(p.l * p.m + k) * kElLinWords;
+            Wk[k] = reinterpret_cast<const float*>(te[0]);
+            ldwk[k] = (int)te[6];
+            const int K = k == 0 ? Fin : H;
+            if (tid < H) {
+                const float gam = reinterpret_cast<const float*>(te[2])[tid], bet = reinterpret_cast<const float*>(te[3])[tid];
+                const float rm = reinterpret_cast<const float*>(te[4])[tid], rv = reinterpret_cast<const float*>(te[5])[tid];
+                const float rstd = (float)(1.0 / sqrt((double)rv + (double)p.bn_eps));
+                const float sc = gam * rstd;
+                aff[k][0][tid] = reinterpret_cast<const float*>(te[1])[tid];
+                aff[k][1][tid] = sc;
+                aff[k][2][tid] = bet - rm * sc;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k0 = 16 * (khB + KSB * u) + 8 * h;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fbw[k][u][j] = k0 + j < K ? Wk[k][(size_t)ncolB * ldwk[k] + k0 + j] : 0.f;
+            }
+        }
+    }
     // ---- A. aggregation ----------------------------------------------------------------------------------------
     const int NCA = Fin <= 32 ? 1 : (Fin <= 64 ? 2 : 4);          // column tiles of the input; the rest of the waves split k
     // the combine pass's own operands (8 threads per tile row): this thread's elements of the self term and its row's
@@ -95,12 +130,9 @@ __global__ void __launch_bounds__(256) gnm_eval_layer_kernel(const ElArgs p) {
     const int row = tid >> 3, c8 = tid & 7;
     const int grow = row0 + min(rb * 32 + row, n - 1);
     const bool vrow = rb * 32 + row < n;
-    float hin[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int c = c8 + 8 * q;
-        hin[q] = (c < NCA * 32 && c < Fin) ? p.Hin[(size_t)grow * p.ldin + c] : 0.f;
-    }
+    // (parked in the second LDS tile, which the MLP does not touch before the combine pass has read it)
+    for (int c = c8; c < NCA * 32; c += 8)
+        T1[row * kElTS + c] = c < Fin ? p.Hin[(size_t)grow * p.ldin + c] : 0.f;
     float deg = 1.f;
     if (p.average) {
         const int32_t* rp = p.rowptr + p.b_rp_off[b];
@@ -110,15 +142,16 @@ __global__ void __launch_bounds__(256) gnm_eval_layer_kernel(const ElArgs p) {
     {
         const int ct = wave % NCA, kh = wave / NCA, KS = 4 / NCA;
         const int HPW = (((W + 1) >> 1) + 3) & ~3;
-        unsigned pk[8];
-        {
+        {   // this lane's half row of the block's adjacency bits -> LDS, one word per (word index, thread): the step loop
+            // below is a real loop (fully unrolled, 26 steps x 3 Linears were 54 KB of straight-line code that every
+            // workgroup ran once from a cold instruction cache: 17 us per launch, two thirds of it instruction fetch)
             const uint32_t* gbits = p.adj_bits + p.b_bits_off[b];
             const el_u32x4* rp = reinterpret_cast<const el_u32x4*>(gbits + (size_t)(rb * 32 + i) * (2 * HPW) + h * HPW);
             const el_u32x4 z4 = {0u, 0u, 0u, 0u};
             const el_u32x4 a0 = rp[0];
             const el_u32x4 a1 = HPW > 4 ? rp[1] : z4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { pk[j] = a0[j]; pk[4 + j] = a1[j]; }
+            for (int j = 0; j < 4; ++j) { bitsw[j][tid] = a0[j]; bitsw[4 + j][tid] = a1[j]; }
         }
         const unsigned xbytes = (unsigned)(((size_t)(n - 1) * p.ldin + Fin) * 4);
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -134,32 +167,31 @@ __global__ void __launch_bounds__(256) gnm_eval_layer_kernel(const ElArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xvo, (16 * s + j) * xrow, 0));
         };
-        // (a workgroup is alone on its CU and these are L2 hits of ~1 us: five steps are kept in flight)
-        constexpr int PD = 5;
-        float hb[PD + 1][8];
-#pragma unroll
-        for (int u = 0; u < PD; ++u) request(hb[u], kh + KS * u);
-#pragma unroll
-        for (int u = 0; u < 26; ++u) {                            // this wave's steps s = kh + KS u
-            const int s = kh + KS * u;
-            if (s < ksteps) {                                     // wave-uniform
-                request(hb[(u + PD) % (PD + 1)], s + PD * KS);
-                el_bf16x8 a1, a2, a3;
-                el_split8(hb[u % (PD + 1)], a1, a2, a3);
-                // the 8 bits of (row 32 rb + i, columns 16 s + 8 h ..): byte s & 3 of word s >> 2 of this lane's half row
-                const int wsel = s >> 2;
-                const unsigned pkw = wsel == 0 ? pk[0] : wsel == 1 ? pk[1] : wsel == 2 ? pk[2] : wsel == 3 ? pk[3] :
-                                     wsel == 4 ? pk[4] : wsel == 5 ? pk[5] : wsel == 6 ? pk[6] : pk[7];
-                const unsigned byte3 = ((pkw >> (8 * (s & 3))) & 0xFFu) << 3;
-                const unsigned lo = byte3 & 0x78u, hi = (byte3 >> 4) & 0x78u;
-                const el_u32x2 l2 = *reinterpret_cast<const el_u32x2*>(lut + lo);
-                const el_u32x2 h2 = *reinterpret_cast<const el_u32x2*>(lut + hi);
-                const el_u32x4 q = {l2.x, l2.y, h2.x, h2.y};
-                const el_bf16x8 bq = __builtin_bit_cast(el_bf16x8, q);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bq, acc, 0, 0, 0);      // small planes first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc, 0, 0, 0);
-            }
+        auto multiply = [&](const float (&d)[8], int s) {
+            el_bf16x8 a1, a2, a3;
+            el_split8(d, a1, a2, a3);
+            // the 8 bits of (row 32 rb + i, columns 16 s + 8 h ..): byte s & 3 of word s >> 2 of this lane's half row
+            const unsigned pkw = bitsw[s >> 2][tid];
+            const unsigned byte3 = ((pkw >> (8 * (s & 3))) & 0xFFu) << 3;
+            const unsigned lo = byte3 & 0x78u, hi = (byte3 >> 4) & 0x78u;
+            const el_u32x2 l2 = *reinterpret_cast<const el_u32x2*>(lut + lo);
+            const el_u32x2 h2 = *reinterpret_cast<const el_u32x2*>(lut + hi);
+            const el_u32x4 q = {l2.x, l2.y, h2.x, h2.y};
+            const el_bf16x8 bq = __builtin_bit_cast(el_bf16x8, q);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, bq, acc, 0, 0, 0);      // small planes first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bq, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bq, acc, 0, 0, 0);
+        };
+        // this wave's steps s = kh + KS u, four to an iteration, three requests ahead of the one being multiplied
+        float hb0[8], hb1[8], hb2[8], hb3[8];
+        request(hb0, kh); request(hb1, kh + KS); request(hb2, kh + 2 * KS);
+#pragma nounroll
+        for (int s = kh; s < ksteps; s += 4 * KS) {               // wave-uniform
+            request(hb3, s + 3 * KS);
+            multiply(hb0, s);
+            if (s + KS < ksteps) { request(hb0, s + 4 * KS); multiply(hb1, s + KS); }
+            if (s + 2 * KS < ksteps) { request(hb1, s + 5 * KS); multiply(hb2, s + 2 * KS); }
+            if (s + 3 * KS < ksteps) { request(hb2, s + 6 * KS); multiply(hb3, s + 3 * KS); }
         }
         // accumulator (r, lane): input column 32 ct + (r & 3) + 8 (r >> 2) + 4 h, output row i
 #pragma unroll
@@ -170,65 +202,36 @@ __global__ void __launch_bounds__(256) gnm_eval_layer_kernel(const ElArgs p) {
         const int KP = (Fin + 15) & ~15;                          // the first Linear's contraction width (zero padded)
         const int KS = 4 / NCA;
         const float selfw = p.eps ? 1.f + p.eps[p.l] : 1.f;       // graphcnn.py:161 (1 + eps[layer]) h
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int c = c8 + 8 * q;
-            if (c < NCA * 32) {
-                float v = 0.f;
-                for (int k = 0; k < KS; ++k) v += part[(c >> 5) + NCA * k][row][c & 31];
-                if (p.self_loop) v += hin[q];
-                if (p.average) v /= deg;                          // 0 / 0 -> NaN as in the reference
-                if (!p.self_loop) v += selfw * hin[q];
-                if (c < KP) T0[row * kElTS + c] = (vrow && c < Fin) ? v : 0.f;
-            }
+        for (int c = c8; c < NCA * 32; c += 8) {
+            float v = 0.f;
+            for (int k = 0; k < KS; ++k) v += part[(c >> 5) + NCA * k][row][c & 31];
+            const float hin = T1[row * kElTS + c];
+            if (p.self_loop) v += hin;
+            if (p.average) v /= deg;                              // 0 / 0 -> NaN as in the reference
+            if (!p.self_loop) v += selfw * hin;
+            if (c < KP) T0[row * kElTS + c] = (vrow && c < Fin) ? v : 0.f;
         }
     }
     // ---- B. the MLP --------------------------------------------------------------------------------------------
-    const int NCT = H >> 5, KSB = 4 / NCT;
     float* Tin = T0;
     float* Tout = T1;
-    for (int k = 0; k < p.m; ++k) {
-        const long long* te = p.table + (size_t)(p.l * p.m + k) * kElLinWords;
-        const float* Wk = reinterpret_cast<const float*>(te[0]);
-        const int ldw = (int)te[6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k >= p.m) break;                                      // workgroup-uniform
         const int K = k == 0 ? Fin : H;
-        if (tid < H) {
-            const float gam = reinterpret_cast<const float*>(te[2])[tid], bet = reinterpret_cast<const float*>(te[3])[tid];
-            const float rm = reinterpret_cast<const float*>(te[4])[tid], rv = reinterpret_cast<const float*>(te[5])[tid];
-            const float rstd = (float)(1.0 / sqrt((double)rv + (double)p.bn_eps));
-            const float sc = gam * rstd;
-            aff[0][tid] = reinterpret_cast<const float*>(te[1])[tid];
-            aff[1][tid] = sc;
-            aff[2][tid] = bet - rm * sc;
-        }
-        // this wave's rows of W (the B operand) do not depend on the tile: requested before the barrier.  At most
-        // 8 steps (K = 128, one k range), usually 2.
-        const int ct = wave % NCT, kh = wave / NCT;
+        const int ct = ctB, kh = khB, ncol = ncolB;
         const int nst = (K + 15) >> 4;
-        const int ncol = 32 * ct + i;                             // output column = row of W
-        float fbw[8][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k0 = 16 * (kh + KSB * u) + 8 * h;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) fbw[u][j] = k0 + j < K ? Wk[(size_t)ncol * ldw + k0 + j] : 0.f;
-        }
-        __syncthreads();                                          // the input tile and the vectors are complete
+        __syncthreads();                                          // the input tile (and, the first time, the vectors) complete
         {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int s = kh + KSB * u;
-                if (s >= nst) break;                              // wave-uniform
+            auto stepB = [&](const float (&fb)[8], int s) {
                 const int k0 = 16 * s + 8 * h;
-                float fa[8], fb[8];
+                float fa[8];
                 const float4 v0 = *reinterpret_cast<const float4*>(Tin + i * kElTS + k0);
                 const float4 v1 = *reinterpret_cast<const float4*>(Tin + i * kElTS + k0 + 4);
                 fa[0] = v0.x; fa[1] = v0.y; fa[2] = v0.z; fa[3] = v0.w; fa[4] = v1.x; fa[5] = v1.y; fa[6] = v1.z; fa[7] = v1.w;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) fb[j] = fbw[u][j];
                 el_bf16x8 a1, a2, a3, b1, b2, b3;
                 el_split8(fa, a1, a2, a3);
                 el_split8(fb, b1, b2, b3);
@@ -238,6 +241,18 @@ __global__ void __launch_bounds__(256) gnm_eval_layer_kernel(const ElArgs p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+            };
+            // the wave's first two steps: W fragments requested at kernel entry; the rest (K = 128 with one k range per
+            // wave) in a real loop, on demand
+            if (kh < nst) stepB(fbw[k][0], kh);
+            if (kh + KSB < nst) stepB(fbw[k][1], kh + KSB);
+#pragma nounroll
+            for (int s = kh + 2 * KSB; s < nst; s += KSB) {
+                const int k0 = 16 * s + 8 * h;
+                float fb[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) fb[j] = k0 + j < K ? Wk[k][(size_t)ncol * ldwk[k] + k0 + j] : 0.f;
+                stepB(fb, s);
             }
             // accumulator (r, lane): tile row (r & 3) + 8 (r >> 2) + 4 h, output column 32 ct + i
 #pragma unroll
@@ -246,9 +261,9 @@ __global__ void __launch_bounds__(256) gnm_eval_layer_kernel(const ElArgs p) {
         __syncthreads();
         const bool last = k == p.m - 1;
         for (int c = c8; c < H; c += 8) {
-            float z = aff[0][c];
+            float z = aff[k][0][c];
             for (int q = 0; q < KSB; ++q) z += part[(c >> 5) + NCT * q][row][c & 31];
-            float y = gnm_relu(z * aff[1][c] + aff[2][c]);        // mlp.py:48 (inner) / graphcnn.py:163-166, 187-190 (outer)
+            float y = gnm_relu(z * aff[k][1][c] + aff[k][2][c]);        // mlp.py:48 (inner) / graphcnn.py:163-166, 187-190 (outer)
             if (last) {
                 if (vrow) p.Hout[(size_t)grow * p.ldh + c] = y;
                 else y = 0.f;                                     // (rows past n: not part of the readout)

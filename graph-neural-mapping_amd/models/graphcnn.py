@@ -160,7 +160,7 @@ class GIN_InfoMaxReg(nn.Module):
         # graph, gpurun_out/r03i_time_eval.log) -- one CU runs a graph's whole chain (MFMA floor ~57 us + 50 barriers)
         # where the ~110 replayed launches (~1.4 us apiece) each spread over several CUs.  DESIGN.md section 6.
         # eval_fused = "layers": one launch per LAYER with a workgroup per 32-row block of every graph
-        # (csrc/evallayer.hip): 13 CUs work on a 400-node graph, ~10 launches per forward.  0.136 ms per graph -- the
+        # (csrc/evallayer.hip): 13 CUs work on a 400-node graph, ~10 launches per forward.  0.130 ms per graph -- the
         # default.  False: the training kernels in eval mode.
         self.eval_fused = "layers"
 
