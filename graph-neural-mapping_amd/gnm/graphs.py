@@ -181,7 +181,12 @@ class CapturedEval:
         m = self.model
         bt = self.static.batch
         with torch.no_grad():
-            X, P0 = bt.arena.features_and_agg0(bt, m._spec.n_avg, not m._spec.learn_eps)
+            if getattr(m, "eval_fused", False):
+                # the evaluation encoders aggregate layer 0 themselves (a shape they decline takes the differentiable
+                # path, which then does so too): no gather from the arena's layer-0 cache
+                X, P0 = bt.arena.features(bt), None
+            else:
+                X, P0 = bt.arena.features_and_agg0(bt, m._spec.n_avg, not m._spec.learn_eps)
             return m._run(bt, X, self.perm, want_disc=True, P0=P0)
 
     def valid_for(self, gh):
