@@ -40,6 +40,11 @@ struct LinArgs {
     unsigned long long* stamps;   // tuning builds only (gnm_debug_set_lin_stamps): [block][4 waves][64] s_memtime
     int stat_rows;           // gnm_lin_split_kernel: rows of stats_partial = groups of four waves that take tiles
     int stage_out;           // gnm_lin_kernel: the launch reserved LDS for the output staging image
+    // gnm_lin_split128_kernel, dX form (gnm_linear_dgrad_masked): the output is the gradient arriving at relu(bn(mZ)) of
+    // the BatchNorm + ReLU below -- apply that ReLU mask on the way out and reduce that BatchNorm's backward sums
+    // (sum G, sum G xhat) into stats_partial instead of the forward's (sum Z, sum Z^2)
+    const float* mZ; const float* m_scale; const float* m_shift; const float* m_mean; const float* m_rstd;
+    int ldmz;
 };
 
 // First tile of a wave in the strided tile walk (stride = all active waves of the launch).  Numbering the waves
@@ -964,6 +969,7 @@ static int launch_lin_split(const LinArgs& a0, int grid, hipStream_t s) {
 // ---------------------------------------------------------------------------------
 static constexpr int kSplit128Waves = 12;
 
+template <bool MASKED>
 __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(const LinArgs p) {
     constexpr int K = 128, HT = 4, HP = 128, NW = kSplit128Waves, NT = NW * 64;
     constexpr int E = 2 * 4 * HT * 64;              // 16-byte operand entries per weight plane: [kk][m][c][lane]
@@ -1063,6 +1069,49 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
         }
         // ---- epilogue: bias, column statistics, stores (lane = column; rows past N clipped by the descriptor) ----
         const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, rows, p.ldz, HP);
+        if constexpr (MASKED) {
+            // masked dX: the values under the accumulators of the lower BatchNorm's input (lane = column: 128-byte row
+            // pieces), one column block requested ahead of the one being finished
+            const __amdgpu_buffer_rsrc_t rm = gnm_tile_rsrc(p.mZ + (size_t)r0 * p.ldmz, rows, p.ldmz, HP);
+            // (one vector offset per lane and the (row, column block) part in the scalar offset: with a vector offset per
+            //  element the compiler kept 128 of them across the tile loop -- 77 spilled registers)
+            const unsigned mvo = (unsigned)((4 * h * p.ldmz + i) * 4), zvo = (unsigned)((4 * h * p.ldz + i) * 4);
+            float zm[2][16];
+            auto req = [&](float (&d)[16], int c) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    d[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        rm, mvo, (((r & 3) + 8 * (r >> 2)) * p.ldmz + 32 * c) * 4, 0));
+            };
+            __builtin_amdgcn_sched_barrier(0);            // (hoisted into the product loop these requests spilled 77 registers)
+            req(zm[0], 0);
+#pragma unroll
+            for (int c = 0; c < HT; ++c) {
+                if (c + 1 < HT) req(zm[(c + 1) & 1], c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const int col = 32 * c + i;
+                const float msc = p.m_scale[col], msh = p.m_shift[col], mmu = p.m_mean[col];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float zv = zm[c & 1][r];
+                    float g = acc[c][r];
+                    if (!(zv * msc + msh > 0.f)) g = 0.f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(g), rz, zvo, (((r & 3) + 8 * (r >> 2)) * p.ldz + 32 * c) * 4, 0);
+                    if (lrow < rows) {
+                        s1 += g;
+                        s2 += g * (zv - mmu);
+                    }
+                }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (h == 0) {
+                    wst[col] += (double)s1;
+                    wst[HP + col] += (double)s2 * (double)p.m_rstd[col];      // sum G (Z - mean) rstd = sum G xhat
+                }
+            }
+        } else {
 #pragma unroll
         for (int c = 0; c < HT; ++c) {
             float s1 = 0.f, s2 = 0.f;
@@ -1083,6 +1132,7 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
                 wst[32 * c + i] += (double)s1;
                 wst[HP + 32 * c + i] += (double)s2;
             }
+        }
         }
     }
 
@@ -1106,8 +1156,13 @@ static int launch_lin_split128(const LinArgs& a0, int grid, hipStream_t s) {
     a.stat_rows = grid;
     const int grid3 = (grid + 2) / 3;
     const size_t lds = (size_t)3 * (2 * 4 * 4 * 64) * 16 + (size_t)3 * 128 * 4 + (size_t)kSplit128Waves * 2 * 128 * 8;
-    GNM_ALLOW_FULL_LDS((&gnm_lin_split128_kernel));
-    hipLaunchKernelGGL(gnm_lin_split128_kernel, dim3(grid3), dim3(kSplit128Waves * 64), lds, s, a);
+    if (a.mZ) {
+        GNM_ALLOW_FULL_LDS((&gnm_lin_split128_kernel<true>));
+        hipLaunchKernelGGL(gnm_lin_split128_kernel<true>, dim3(grid3), dim3(kSplit128Waves * 64), lds, s, a);
+    } else {
+        GNM_ALLOW_FULL_LDS((&gnm_lin_split128_kernel<false>));
+        hipLaunchKernelGGL(gnm_lin_split128_kernel<false>, dim3(grid3), dim3(kSplit128Waves * 64), lds, s, a);
+    }
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }
@@ -1180,6 +1235,7 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
     a.stats_partial = stats_partial; a.ldx = ldx; a.ldw = ldw; a.ldz = ldz; a.N = N; a.K = K; a.H = H;
     a.w_kmajor = w_kmajor; a.pro_relu = pro_relu;
     a.stat_rows = 0; a.stage_out = 0;
+    a.mZ = nullptr; a.m_scale = a.m_shift = a.m_mean = a.m_rstd = nullptr; a.ldmz = 0;
 #ifdef GNM_LIN_TUNING
     a.stamps = g_lin_stamps;
 #else
@@ -1225,6 +1281,28 @@ extern "C" int gnm_linear_fwd(const float* X, int ldx, const float* W, int ldw, 
     GNM_LIN_CASE(64, 1) GNM_LIN_CASE(64, 2) GNM_LIN_CASE(64, 3) GNM_LIN_CASE(64, 4)
 #undef GNM_LIN_CASE
     return GNM_ERR_UNSUPPORTED;
+}
+
+// dX = dZ W for a K = H = 128 Linear whose input came through BatchNorm + ReLU (mlp.py:48), with that ReLU's mask and
+// that BatchNorm's backward sums taken on the way out (replaces gnm_linear_fwd(w_kmajor = 1) + gnm_bn_relu_bwd_stats for
+// the inner BatchNorms of an H = 128 model; the K = H = 64 shapes have gnm_linear_bwd_fused):
+//     G[n, k] = (dZ W)[n, k] if relu(mZ[n, k] m_scale[k] + m_shift[k]) > 0 else 0
+//     stats_partial[row][0][k] = partial sum G,  [1][k] = partial sum G (mZ - m_mean) m_rstd     (gnm_linear_grid(N) rows)
+// dZ [N, H = 128], W [H][K = 128] row-major (the Linear's weight), G [N, K].  GNM_ERR_UNSUPPORTED for other shapes.
+extern "C" int gnm_linear_dgrad_masked(const float* dZ, int ldd, const float* W, int ldw, float* G, int ldg, int N, int K,
+                                       int H, const float* mZ, int ldmz, const float* m_scale, const float* m_shift,
+                                       const float* m_mean, const float* m_rstd, double* stats_partial, void* stream) {
+    if (N <= 0) return GNM_OK;
+    if (K != 128 || H != 128 || lin_no_split() || lin_force_generic()) return GNM_ERR_UNSUPPORTED;
+    if (!dZ || !W || !G || !mZ || !m_scale || !m_shift || !m_mean || !m_rstd || !stats_partial) return GNM_ERR_BAD_ARG;
+    if ((ldd & 3) || (reinterpret_cast<uintptr_t>(dZ) & 15)) return GNM_ERR_UNSUPPORTED;
+    if ((long long)(ldd > ldg ? (ldd > ldmz ? ldd : ldmz) : (ldg > ldmz ? ldg : ldmz)) * 32 * 4 >= (1LL << 31)) return GNM_ERR_UNSUPPORTED;
+    LinArgs a;
+    a.X = dZ; a.W = W; a.bias = nullptr; a.Z = G; a.pro_scale = nullptr; a.pro_shift = nullptr;
+    a.stats_partial = stats_partial; a.ldx = ldd; a.ldw = ldw; a.ldz = ldg; a.N = N; a.K = H; a.H = K;
+    a.w_kmajor = 1; a.pro_relu = 0; a.stamps = nullptr; a.stat_rows = 0; a.stage_out = 0;
+    a.mZ = mZ; a.m_scale = m_scale; a.m_shift = m_shift; a.m_mean = m_mean; a.m_rstd = m_rstd; a.ldmz = ldmz;
+    return launch_lin_split128(a, gnm_linear_grid(N), reinterpret_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------

@@ -302,6 +302,9 @@ def _linear_wide(x, W, w_kmajor, bias, z, N, K, H, pro, stats):
 RZ_BACKWARD = os.environ.get("GNM_NO_RZ", "0") != "1"
 
 
+# GNM_NO_MASKED_DGRAD=1: the H = 128 Linears' dX without the fused ReLU mask / BatchNorm sums (A/B timing, tests)
+MASKED_DGRAD = os.environ.get("GNM_NO_MASKED_DGRAD", "0") != "1"
+
 # the three [B, L*H]-sized products of the Infomax tail on the hand-written kernel (csrc/sgemm.hip); GNM_NO_SGEMM=1
 # keeps torch.mm (hipBLASLt) for A/B timing
 SMALL_GEMM = os.environ.get("GNM_NO_SGEMM", "0") != "1"
@@ -967,7 +970,21 @@ class GinInfoMaxFn(torch.autograd.Function):
                                                    dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(), st),
                               "gnm_linear_wgrad")
                     if need_dA:
-                        _linear_wide(dZ, W, 1, None, dA, N, Hk, K, None, None)      # dX = dZ W
+                        rc2 = -2
+                        if lo is not None and K == 128 and Hk == 128 and MASKED_DGRAD:
+                            # dX = dZ W with the ReLU mask of the BatchNorm + ReLU below and that BatchNorm's backward
+                            # sums taken in the epilogue (replaces its gnm_bn_relu_bwd_stats pass)
+                            lo_part = torch.empty((int(lib.gnm_linear_grid(N)), 2, K), dtype=torch.float64, device=dev)
+                            rc2 = lib.gnm_linear_dgrad_masked(
+                                dZ.data_ptr(), dZ.stride(0), W.data_ptr(), W.stride(0), dA.data_ptr(), dA.stride(0), N, K,
+                                Hk, lo.z.data_ptr(), lo.z.stride(0), lo.scale.data_ptr(), lo.shift.data_ptr(),
+                                lo.mean.data_ptr(), lo.rstd.data_ptr(), lo_part.data_ptr(), st)
+                            if rc2 == 0:
+                                pre_stats = (dA, lo_part, lo_part.shape[0])
+                            elif rc2 != -2:
+                                check(rc2, "gnm_linear_dgrad_masked")
+                        if rc2 == -2:
+                            _linear_wide(dZ, W, 1, None, dA, N, Hk, K, None, None)      # dX = dZ W
                 else:
                     check(rc, "gnm_linear_bwd_fused")
                 if sink is None:

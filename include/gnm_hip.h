@@ -204,6 +204,15 @@ int gnm_linear_bwd_fused_rz(const float* G, int ldg, const float* bias, const fl
                             float* dA, int lda, float* dW, int lddw, float* db, float* workspace, int N, int K, int H,
                             const float* sZ, int ldsz, const float* s_scale, const float* s_shift, const float* s_mean,
                             const float* s_rstd, double* s_partial, void* stream);
+
+/* dX = dZ W of a K = H = 128 Linear whose input came through BatchNorm + ReLU (mlp.py:48), with that ReLU's mask and that
+ * BatchNorm's backward sums in the epilogue (replaces gnm_linear_fwd(w_kmajor = 1) + gnm_bn_relu_bwd_stats for the inner
+ * BatchNorms of an H = 128 model):  G[n,k] = (dZ W)[n,k] where mZ[n,k] m_scale[k] + m_shift[k] > 0, else 0;
+ * stats_partial [gnm_linear_grid(N)][2][K]: partial sums of G and of G (mZ - m_mean) m_rstd, as gnm_bn_bwd_finalize takes
+ * them.  W [H][K] row-major (the Linear's weight).  GNM_ERR_UNSUPPORTED for other shapes. */
+int gnm_linear_dgrad_masked(const float* dZ, int ldd, const float* W, int ldw, float* G, int ldg, int N, int K, int H,
+                            const float* mZ, int ldmz, const float* m_scale, const float* m_shift, const float* m_mean,
+                            const float* m_rstd, double* stats_partial, void* stream);
 /* dW = NULL defers the reduction of the per-workgroup dW / db partials: they stay in `workspace` (keep it alive and
  * unshared) until ONE gnm_reduce_partials_multi call reduces up to 32 such workspaces of the same N, e.g. at the end
  * of a backward pass (nothing in the backward reads a weight gradient).  HOST arrays of njobs entries. */

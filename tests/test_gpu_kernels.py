@@ -1174,3 +1174,32 @@ def test_small_gemm_all_operand_forms(M, N, K):
                 err = np.abs(outs[0][:, :N] - ref) / bound
                 assert err.max() < 1e-6, (a_cols, b_cols, off, err.max())
                 assert np.array_equal(outs[0][:, :N], outs[1][:, :N])
+
+
+@pytest.mark.parametrize("N", [1, 77, 5000 + 3])
+def test_masked_dgrad_k128(N):
+    """gnm_linear_dgrad_masked (K = H = 128): dX = dZ W with the lower ReLU's mask and the lower BatchNorm's backward sums
+    in the epilogue, against fp64"""
+    from gnm._cabi import check, lib
+    K = H = 128
+    rng = np.random.default_rng(N)
+    dZ = rng.standard_normal((N, H)).astype(np.float32)
+    W = (rng.standard_normal((H, K)) / 11).astype(np.float32)
+    mZ = rng.standard_normal((N, K)).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, K).astype(np.float32), (rng.standard_normal(K) * 0.3).astype(np.float32)
+    mu, rs = rng.standard_normal(K).astype(np.float32), rng.uniform(0.5, 1.5, K).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    dZd, Wd, mZd, scd, shd, mud, rsd = map(t, (dZ, W, mZ, sc, sh, mu, rs))
+    G = torch.full((N, K), float("nan"), device=DEV)
+    grid = int(lib.gnm_linear_grid(N))
+    part = torch.full((grid, 2, K), float("nan"), dtype=torch.float64, device=DEV)
+    check(lib.gnm_linear_dgrad_masked(dZd.data_ptr(), H, Wd.data_ptr(), K, G.data_ptr(), K, N, K, H, mZd.data_ptr(), K,
+                                      scd.data_ptr(), shd.data_ptr(), mud.data_ptr(), rsd.data_ptr(), part.data_ptr(),
+                                      _stream()), "gnm_linear_dgrad_masked")
+    ref = dZ.astype(np.float64) @ W.astype(np.float64)
+    ref = ref * ((mZ * sc + sh) > 0)
+    assert_close(G.cpu().numpy(), ref, rtol=TOL, what="masked dX")
+    ps = part.sum(0).cpu().numpy()
+    xhat = (mZ.astype(np.float64) - mu) * rs
+    assert_close(ps[0], ref.sum(0), rtol=TOL, what="sum G", floor=np.abs(ref).sum(0).max() * 1e-6)
+    assert_close(ps[1], (ref * xhat).sum(0), rtol=TOL, what="sum G xhat", floor=np.abs(ref * xhat).sum(0).max() * 1e-6)
