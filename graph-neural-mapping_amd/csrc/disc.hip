@@ -314,14 +314,14 @@ extern "C" int gnm_disc_score_fwd_unit(const float* const* hptrs, const float* c
                              d_logit, unit, ldunit, inv_perm, stream);
 }
 
-// dU = k unit[:, :LH], s2sum = k unit[:, LH], dsum = k unit[:, LH + 1]; k a device scalar (the loss's factor times the
-// upstream gradient).  What gnm_disc_score_bwd would have produced from dD = k (sigmoid(d_logit) - target).
+// dU = k unit[:, :LH], s2sum = k unit[:, LH], dsum = k unit[:, LH + 1] with k = *k_dev x kscale: the upstream gradient (a
+// device scalar) times the loss's host-side factor -- multiplied here, not by an element-wise launch of the caller.  What gnm_disc_score_bwd would have produced from dD = k (sigmoid(d_logit) - target).
 __global__ void __launch_bounds__(256) gnm_disc_unit_scale_kernel(const float* __restrict__ unit, int ldunit, int LH,
-                                                                  const float* __restrict__ k, float* __restrict__ dU,
-                                                                  int ldu, float* __restrict__ s2sum,
-                                                                  float* __restrict__ dsum) {
+                                                                  const float* __restrict__ k, float kscale,
+                                                                  float* __restrict__ dU, int ldu,
+                                                                  float* __restrict__ s2sum, float* __restrict__ dsum) {
     const int g = blockIdx.x;
-    const float kv = *k;
+    const float kv = *k * kscale;                 // (one fp32 product, as the loss-gradient kernel forms its factor)
     const float* row = unit + (size_t)g * ldunit;
     for (int e = threadIdx.x; e < LH; e += blockDim.x) dU[(size_t)g * ldu + e] = kv * row[e];
     if (threadIdx.x == 0) {
@@ -330,12 +330,12 @@ __global__ void __launch_bounds__(256) gnm_disc_unit_scale_kernel(const float* _
     }
 }
 
-extern "C" int gnm_disc_unit_scale(const float* unit, int ldunit, int LH, const float* k, int B, float* dU, int ldu,
-                                   float* s2sum, float* dsum, void* stream) {
+extern "C" int gnm_disc_unit_scale(const float* unit, int ldunit, int LH, const float* k, float kscale, int B, float* dU,
+                                   int ldu, float* s2sum, float* dsum, void* stream) {
     if (B <= 0) return GNM_OK;
     if (!unit || !k || !dU || !s2sum || LH <= 0 || ldunit < LH + 2) return GNM_ERR_BAD_ARG;
     hipLaunchKernelGGL(gnm_disc_unit_scale_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), unit,
-                       ldunit, LH, k, dU, ldu, s2sum, dsum);
+                       ldunit, LH, k, kscale, dU, ldu, s2sum, dsum);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }

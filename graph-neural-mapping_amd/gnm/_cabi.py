@@ -75,7 +75,7 @@ SIGNATURES = {
                              _p, _i, _p, _p, _i, _p]),
     "gnm_disc_score_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p]),
     "gnm_disc_score_fwd_unit": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p]),
-    "gnm_disc_unit_scale": (_i, [_p, _i, _i, _p, _i, _p, _i, _p, _p, _p]),
+    "gnm_disc_unit_scale": (_i, [_p, _i, _i, _p, _f, _i, _p, _i, _p, _p, _p]),
     "gnm_disc_score_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p]),
     "gnm_head_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     "gnm_head_bwd": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),

@@ -458,10 +458,11 @@ class DiscUnit:
     Any other loss (main.py's torch losses, explicit d_labels, a d_logit that also feeds something else so that
     autograd SUMS gradients into a new tensor) leaves k unset or the pointer different, and the backward runs
     gnm_disc_score_bwd exactly as before."""
-    __slots__ = ("unit", "inv_perm", "k", "dD_ptr")
+    __slots__ = ("unit", "inv_perm", "k", "kscale", "dD_ptr")
 
     def __init__(self):
         self.unit = self.inv_perm = self.k = self.dD_ptr = None
+        self.kscale = 1.0
 
 
 # GNM_NO_DISC_UNIT=1: never produce the by-products (A/B timing against gnm_disc_score_bwd's pass)
@@ -655,7 +656,11 @@ class GinInfoMaxFn(torch.autograd.Function):
         Cn = wps[0].shape[0]
         masks = None
         if training and dropout_p > 0:
-            masks = F.dropout(torch.ones((L, B, Cn), dtype=torch.float32, device=X.device), dropout_p, True)  # :230
+            # (F.dropout of a cached tensor of ones: the fill it would otherwise need is a launch per step)
+            ones = getattr(spec, "_ones_mask", None)
+            if ones is None or ones.shape != (L, B, Cn) or ones.device != X.device:
+                ones = spec._ones_mask = torch.ones((L, B, Cn), dtype=torch.float32, device=X.device)
+            masks = F.dropout(ones, dropout_p, True)                                                      # :230
         c_logit = torch.empty((B, Cn), dtype=torch.float32, device=X.device)
         c = torch.empty_like(g_f) if want_disc else None
         fused_head = all(w.is_contiguous() for w in wps) and all(b_.is_contiguous() for b_ in bps)
@@ -776,7 +781,8 @@ class GinInfoMaxFn(torch.autograd.Function):
                 # dD = k (sigmoid(d_logit) - target) came straight from the loss that recorded k: the reductions are k
                 # times what the forward left (DiscUnit) -- no second pass over the hidden layers
                 inv_perm = hold.inv_perm
-                check(lib.gnm_disc_unit_scale(hold.unit.data_ptr(), hold.unit.stride(0), L * H, hold.k.data_ptr(), B,
+                check(lib.gnm_disc_unit_scale(hold.unit.data_ptr(), hold.unit.stride(0), L * H, hold.k.data_ptr(),
+                                              float(getattr(hold, "kscale", 1.0)), B,
                                               dU.data_ptr(), dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(), st),
                       "gnm_disc_unit_scale")
             else:

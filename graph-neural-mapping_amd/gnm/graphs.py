@@ -93,7 +93,11 @@ class CapturedTrainStep:
         X = None if self._agg0_cache else bt.arena.features(bt)
         c_logit, d_logit = self.model.forward_batch(bt, X=X, perm=self.perm)
         loss = self._loss_fn(c_logit, d_logit, self.labels)
-        loss.backward()
+        # (the root gradient is a cached one: loss.backward() alone fills a fresh tensor with 1.0 -- a launch per step)
+        one = getattr(self, "_one", None)
+        if one is None or one.shape != loss.shape or one.dtype != loss.dtype or one.device != loss.device:
+            one = self._one = torch.ones_like(loss)
+        loss.backward(one)
         if self._post is not None:
             self._post()
         return loss

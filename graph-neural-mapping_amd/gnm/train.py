@@ -71,7 +71,8 @@ class _InfomaxLossFn(torch.autograd.Function):
         if ctx.hold is not None:
             # dD = k (sigmoid(d_logit) - target) with the kernel's fp32 factor k = upstream * (beta / M): the model's
             # backward scales the reductions its forward left instead of re-reading the hidden layers
-            ctx.hold.k = g.reshape(1) * float(np.float32(beta) / np.float32(M))
+            ctx.hold.k = g.reshape(1)
+            ctx.hold.kscale = float(np.float32(beta) / np.float32(M))
             ctx.hold.dD_ptr = dD.data_ptr()
         return dC, dD, None, None, None, None, None
 

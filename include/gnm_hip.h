@@ -317,7 +317,7 @@ int gnm_disc_score_fwd_unit(const float* const* hptrs_host, const float* const* 
                             const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
                             float* d_logit, float* unit, int ldunit, int32_t* inv_perm, void* stream);
 /* dU = k * unit[:, :LH], s2sum = k * unit[:, LH], dsum = k * unit[:, LH + 1] (dsum may be NULL); k: DEVICE scalar. */
-int gnm_disc_unit_scale(const float* unit, int ldunit, int LH, const float* k, int B, float* dU, int ldu,
+int gnm_disc_unit_scale(const float* unit, int ldunit, int LH, const float* k, float kscale, int B, float* dU, int ldu,
                         float* s2sum, float* dsum, void* stream);
 /* optional by-products: dsum[g] = sum over graph g of dD (both halves; their total is d bias), and
  * inv_perm[perm_rows[g]] = g. */

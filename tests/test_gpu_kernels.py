@@ -765,7 +765,7 @@ def test_discriminator_unit_reductions_equal_the_backward_pass(B, n, L, H, as_z)
     dD64 = float(k) * (1.0 / (1.0 + np.exp(-x64)) - tgt)
     kd = t(np.array([k], dtype=np.float32))
     dU, s2, dsum = torch.empty((B, LH), device=DEV), torch.empty(B, device=DEV), torch.empty(B, device=DEV)
-    check(lib.gnm_disc_unit_scale(unit.data_ptr(), ldunit, LH, kd.data_ptr(), B, dU.data_ptr(), LH, s2.data_ptr(),
+    check(lib.gnm_disc_unit_scale(unit.data_ptr(), ldunit, LH, kd.data_ptr(), 1.0, B, dU.data_ptr(), LH, s2.data_ptr(),
                                   dsum.data_ptr(), _stream()), "unit scale")
     # (a) against the fp64 statement of the reductions
     d1, d2 = dD64[:N], dD64[N:]
