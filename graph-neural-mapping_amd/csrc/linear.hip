@@ -2954,6 +2954,252 @@ static int launch_lb_rz(const LbArgs& a, int grid, hipStream_t s) {
     return GNM_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// gnm_linear_bwd_rz_kernel for a NARROW input (K <= 16: the first Linear of the input layer, K = F0 = 7 in the benchmark),
+// H = 64, no lower BatchNorm.  The Z-reading narrow form moves G and Z (210 MB at the headline batch) for an input that
+// is 11 MB; here Z = X W^T + b is one 16-wide MFMA step per column tile, the weight gradient [64 x K] is one column tile
+// (32 accumulators) and dX [32 x K] one: G is the only large stream.  Same structure as the K = 64 kernel (eight waves,
+// two rows of partials per workgroup, G of the next tile requested before the weight-gradient product); X and dX rows
+// are K floats wide and not 16-byte addressable: 4-byte accesses, clipped by their buffer descriptors.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kRzWaves * 64) gnm_linear_bwd_rzn_kernel(const LbArgs p) {
+    constexpr int HP = 64, XS = 68, NW = kRzWaves, NT = NW * 64, TILE = 16 * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* Wf = reinterpret_cast<u32x4*>(smem);                   // [3][2 c][64]: (c, lane = 32 kg + n) = W[32c+n][8kg+j], k < K
+    u32x4* Wb = Wf + 3 * 128;                                     // [3][4 m][64]: (m, lane = 32 kg + n) = W[8m+32kg+j][n], n < K
+    float* Xs_all = reinterpret_cast<float*>(smem + (size_t)(3 * 128 + 3 * 256) * 16);    // [NW][32][XS]
+    float* coef = Xs_all + NW * 32 * XS;                          // [6][64]: mean, rstd, cA, m1, m2, bias
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    float* Xs = Xs_all + wave * 32 * XS;
+    const int K = p.K;
+    for (int e = tid; e < 128; e += NT) {
+        const int n = e & 31, kg = (e >> 5) & 1, c = e >> 6;
+        float f[8];
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 8 * kg + j < K ? p.W[(size_t)(32 * c + n) * p.ldw + 8 * kg + j] : 0.f;
+        lin_split8(f, p1, p2, p3);
+        Wf[e] = p1; Wf[128 + e] = p2; Wf[256 + e] = p3;
+    }
+    for (int e = tid; e < 256; e += NT) {
+        const int n = e & 31, kg = (e >> 5) & 1, m = e >> 6;
+        float f[8];
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = n < K ? p.W[(size_t)(8 * m + 32 * kg + j) * p.ldw + n] : 0.f;
+        lin_split8(f, p1, p2, p3);
+        Wb[e] = p1; Wb[256 + e] = p2; Wb[512 + e] = p3;
+    }
+    for (int idx = tid; idx < 64; idx += NT) {
+        coef[idx] = p.mean[idx]; coef[64 + idx] = p.rstd[idx]; coef[128 + idx] = p.cA[idx];
+        coef[192 + idx] = p.m1[idx]; coef[256 + idx] = p.m2[idx]; coef[320 + idx] = p.bias ? p.bias[idx] : 0.f;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    f32x16 wacc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wacc[a][r] = 0.f;
+    float dbacc[2] = {0.f, 0.f};
+    const int gw = lin_first_tile(wave, NW / 4, p.part_rows);
+    const int ntiles = (p.N + 31) / 32;
+    const int tstride = p.part_rows * 4;
+    const unsigned g_voff = (unsigned)((4 * h * p.ldg + i) * 4);
+    const unsigned kclip = 0x80000000u;                           // past any buffer, no wrap with the row offsets
+    const unsigned xc_voff = i < K ? (unsigned)((4 * h * p.ldx + i) * 4) : kclip;     // X[row(r, h)][i]
+    const unsigned da_voff = i < K ? (unsigned)((4 * h * p.lda + i) * 4) : kclip;     // dX[row(r, h)][i]
+
+    float g[2][16];
+    auto load_next_g = [&](int tile) {
+        const long long row0 = (long long)tile * 32;
+        const long long rows = min((long long)p.N - row0, 32LL);
+        const __amdgpu_buffer_rsrc_t rg = gnm_tile_rsrc(p.G + row0 * p.ldg, rows, p.ldg, HP);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                g[a][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, g_voff + 128 * a, ((r & 3) + 8 * (r >> 2)) * p.ldg * 4, 0));
+    };
+    auto do_tile = [&](int t, int t_next) {
+        const int r0 = t * 32;
+        const int rows = min(p.N - r0, 32);
+        const __amdgpu_buffer_rsrc_t rx = gnm_tile_rsrc(p.X + (size_t)r0 * p.ldx, rows, p.ldx, K);
+        // ---- Z = X W^T: one step of 16 (zero past K) -------------------------------------------------------------
+        float fx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            fx[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rx, 8 * h + j < K ? (unsigned)((i * p.ldx + 8 * h + j) * 4) : kclip, 0, 0));
+        float xv[16];                             // X in the accumulators' row order, column i: the wgrad operand
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            xv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xc_voff, ((r & 3) + 8 * (r >> 2)) * p.ldx * 4, 0));
+        f32x16 dz[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz[c][r] = 0.f;
+        {
+            u32x4 A1, A2, A3;
+            lin_split8(fx, A1, A2, A3);
+            const lin_bf16x8 a1 = __builtin_bit_cast(lin_bf16x8, A1), a2 = __builtin_bit_cast(lin_bf16x8, A2),
+                             a3 = __builtin_bit_cast(lin_bf16x8, A3);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int e = c * 64 + lane;
+                const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wf[e]), b2 = __builtin_bit_cast(lin_bf16x8, Wf[128 + e]),
+                                 b3 = __builtin_bit_cast(lin_bf16x8, Wf[256 + e]);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, dz[c], 0, 0, 0);
+                dz[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, dz[c], 0, 0, 0);
+            }
+        }
+        // ---- dZ = cA (G - m1 - xhat m2) on the accumulators; image for dgrad -----------------------------------------
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int col = 32 * a + i;
+            const float mu = coef[col], rs = coef[64 + col], ca = coef[128 + col], a1 = coef[192 + col],
+                        a2 = coef[256 + col], bz = coef[320 + col];
+            float dsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float z = dz[a][r] + bz;
+                float d = ca * (g[a][r] - a1 - (z - mu) * rs * a2);
+                if (lrow >= rows) d = 0.f;
+                dz[a][r] = d;
+                dsum += d;
+                Xs[lrow * XS + col] = d;
+            }
+            dbacc[a] += dsum;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- dX = dZ W: one column tile (columns past K are zero and not stored) ------------------------------------
+        if (p.dA) {
+            f32x16 dacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[r] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 v0 = *reinterpret_cast<const float4*>(Xs + i * XS + 32 * h + 8 * m);
+                const float4 v1 = *reinterpret_cast<const float4*>(Xs + i * XS + 32 * h + 8 * m + 4);
+                const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                u32x4 A1, A2, A3;
+                lin_split8(f, A1, A2, A3);
+                const lin_bf16x8 x1 = __builtin_bit_cast(lin_bf16x8, A1), x2 = __builtin_bit_cast(lin_bf16x8, A2),
+                                 x3 = __builtin_bit_cast(lin_bf16x8, A3);
+                const int e = m * 64 + lane;
+                const lin_bf16x8 b1 = __builtin_bit_cast(lin_bf16x8, Wb[e]), b2 = __builtin_bit_cast(lin_bf16x8, Wb[256 + e]),
+                                 b3 = __builtin_bit_cast(lin_bf16x8, Wb[512 + e]);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b3, dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3, b1, dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b2, dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b2, dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2, b1, dacc, 0, 0, 0);
+                dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1, b1, dacc, 0, 0, 0);
+            }
+            const __amdgpu_buffer_rsrc_t rd = gnm_tile_rsrc(p.dA + (size_t)r0 * p.lda, rows, p.lda, K);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[r]), rd, da_voff, ((r & 3) + 8 * (r >> 2)) * p.lda * 4, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();          // the dZ image has been read
+        load_next_g(t_next);                      // past the wave's last tile: empty descriptors, no traffic
+        // ---- dW += dZ^T X: both operands from registers, batch rows in the accumulators' order -----------------------
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float f[8];
+            u32x4 p1, p2, p3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = xv[8 * m + j];
+            lin_split8(f, p1, p2, p3);
+            const lin_bf16x8 x1 = __builtin_bit_cast(lin_bf16x8, p1), x2 = __builtin_bit_cast(lin_bf16x8, p2),
+                             x3 = __builtin_bit_cast(lin_bf16x8, p3);
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = dz[a][8 * m + j];
+                lin_split8(f, p1, p2, p3);
+                const lin_bf16x8 d1 = __builtin_bit_cast(lin_bf16x8, p1), d2 = __builtin_bit_cast(lin_bf16x8, p2),
+                                 d3 = __builtin_bit_cast(lin_bf16x8, p3);
+                wacc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, x3, wacc[a], 0, 0, 0);
+                wacc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d3, x1, wacc[a], 0, 0, 0);
+                wacc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, x2, wacc[a], 0, 0, 0);
+                wacc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, x2, wacc[a], 0, 0, 0);
+                wacc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, x1, wacc[a], 0, 0, 0);
+                wacc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, x1, wacc[a], 0, 0, 0);
+            }
+        }
+    };
+    {
+        int t = gw;
+        load_next_g(t);
+        if (t < ntiles) {
+            do_tile(t, t + tstride);
+            for (t += tstride; t < ntiles; t += tstride) do_tile(t, t + tstride);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // ---- dW [64 x K] / db: the waves of each half in a fixed order ----
+    __syncthreads();
+    float* dump = reinterpret_cast<float*>(smem);                 // [NW][2][16][64] + [NW][2][64]
+    float* mine = dump + (size_t)wave * 2 * TILE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[a * TILE + r * 64 + lane] = wacc[a][r];
+    float* dbdump = dump + (size_t)NW * 2 * TILE;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) dbdump[(wave * 2 + a) * 64 + lane] = dbacc[a];
+    __syncthreads();
+    const size_t pstride = (size_t)HP * K + HP;
+    for (int idx = tid; idx < 2 * 2 * TILE; idx += NT) {
+        const int grp = idx / (2 * TILE), rem = idx - grp * 2 * TILE;
+        const int prow = blockIdx.x * 2 + grp;
+        if (prow >= p.part_rows) continue;
+        const int a = rem / TILE;
+        const int rl = rem - a * TILE;
+        const int r = rl >> 6, ln = rl & 63;
+        const int row = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        const int col = ln & 31;
+        if (col >= K) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += dump[(size_t)(4 * grp + w) * 2 * TILE + rem];
+        p.partial[(size_t)prow * pstride + (size_t)row * K + col] = sum;
+    }
+    for (int idx = tid; idx < 2 * 64; idx += NT) {
+        const int grp = idx >> 6, a = (idx >> 5) & 1, ii = idx & 31;
+        const int prow = blockIdx.x * 2 + grp;
+        if (prow >= p.part_rows) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += dbdump[((4 * grp + w) * 2 + a) * 64 + ii] + dbdump[((4 * grp + w) * 2 + a) * 64 + 32 + ii];
+        p.partial[(size_t)prow * pstride + (size_t)HP * K + 32 * a + ii] = sum;
+    }
+}
+
+static int launch_lb_rzn(const LbArgs& a, int grid, hipStream_t s) {
+    size_t lds = (size_t)(3 * 128 + 3 * 256) * 16 + (size_t)kRzWaves * 32 * 68 * 4 + (size_t)6 * 64 * 4;
+    const size_t dump = ((size_t)kRzWaves * 2 * 1024 + (size_t)kRzWaves * 2 * 64) * 4;
+    if (dump > lds) lds = dump;
+    GNM_ALLOW_FULL_LDS((&gnm_linear_bwd_rzn_kernel));
+    hipLaunchKernelGGL(gnm_linear_bwd_rzn_kernel, dim3((grid + 1) / 2), dim3(kRzWaves * 64), lds, s, a);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
 extern "C" int gnm_linear_bwd_grid(int N) {
     int g = ((N + 31) / 32 + 3) / 4;
     static const int cap = gnm_env_int("GNM_LINBWD_GRID", 512);   // tuning knob
@@ -3050,9 +3296,11 @@ extern "C" int gnm_linear_bwd_fused_rz(const float* G, int ldg, const float* bia
                                        double* s_partial, void* stream) {
     static const bool off = gnm_env_int("GNM_LINBWD_NO_RZ", 0) != 0;
     static const bool wg16 = gnm_env_int("GNM_LINBWD_WG16", 1) != 0;     // A/B knob: weight gradient on the bf16 pipe
-    if (off || N <= 0 || K != 64 || H != 64 || !dA || lin_force_generic() || linbwd_no_split()) return GNM_ERR_UNSUPPORTED;
-    if ((ldx & 3) || (lda & 3)) return GNM_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dA)) & 15) return GNM_ERR_UNSUPPORTED;
+    const bool narrow = K >= 1 && K <= 16 && !sZ && !pro_scale;    // the input layer's first Linear (one 16-wide step of Z): gnm_linear_bwd_rzn_kernel
+    if (off || N <= 0 || (K != 64 && !narrow) || H != 64 || (!dA && !narrow) || lin_force_generic() || linbwd_no_split())
+        return GNM_ERR_UNSUPPORTED;
+    if (!narrow && ((ldx & 3) || (lda & 3))) return GNM_ERR_UNSUPPORTED;
+    if (!narrow && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dA)) & 15)) return GNM_ERR_UNSUPPORTED;
     if ((long long)32 * (ldg > ldx ? (ldg > lda ? ldg : lda) : (ldx > lda ? ldx : lda)) * 4 >= (1LL << 31)) return GNM_ERR_UNSUPPORTED;
     const bool samez = sZ != nullptr;
     // the statistics form is correct and tested but measured BEHIND the kernel that reads Z (101.9 vs 99.3 us at the
@@ -3079,7 +3327,8 @@ extern "C" int gnm_linear_bwd_fused_rz(const float* G, int ldg, const float* bia
     const int grid = gnm_linear_bwd_grid(N);
     a.part_rows = grid;
     int rc;
-    if (samez) rc = wg16 ? launch_lb_rz<true, true>(a, grid, s) : launch_lb_rz<true, false>(a, grid, s);
+    if (narrow) rc = launch_lb_rzn(a, grid, s);
+    else if (samez) rc = wg16 ? launch_lb_rz<true, true>(a, grid, s) : launch_lb_rz<true, false>(a, grid, s);
     else rc = wg16 ? launch_lb_rz<false, true>(a, grid, s) : launch_lb_rz<false, false>(a, grid, s);
     if (rc != GNM_OK) return rc;
     if (!dW) return GNM_OK;

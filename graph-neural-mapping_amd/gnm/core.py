@@ -939,13 +939,13 @@ class GinInfoMaxFn(torch.autograd.Function):
                                lo.mean.data_ptr() if lo_part is not None else None,
                                lo.rstd.data_ptr() if lo_part is not None else None, ptr(lo_part), st)
                     rc = -2
-                    if RZ_BACKWARD and K == 64 and Hk == 64 and need_dA:
+                    if RZ_BACKWARD and Hk == 64 and ((K == 64 and need_dA) or (K <= 16 and not sv.pro and lo_part is None)):
                         # sv.z = Linear(sv.x_in) as gnm_linear_fwd left it: the pass recomputes it instead of reading it
                         rc = lib.gnm_linear_bwd_fused_rz(
                             G.data_ptr(), G.stride(0), P[wname + ".bias"].data_ptr(), sv.mean.data_ptr(),
                             sv.rstd.data_ptr(), cA.data_ptr(), m1.data_ptr(), m2.data_ptr(), sv.x_in.data_ptr(),
                             sv.x_in.stride(0), ptr(sv.pro[0]) if sv.pro else None, ptr(sv.pro[1]) if sv.pro else None,
-                            1 if sv.pro else 0, W.data_ptr(), W.stride(0), ptr(dA), dA.stride(0),
+                            1 if sv.pro else 0, W.data_ptr(), W.stride(0), ptr(dA), dA.stride(0) if need_dA else 0,
                             None if DEFER_WGRAD_REDUCE else dW.data_ptr(), dW.stride(0), db.data_ptr(), ws.data_ptr(),
                             N, K, Hk, *lo_args)
                     if rc == -2:

@@ -1203,3 +1203,47 @@ def test_masked_dgrad_k128(N):
     xhat = (mZ.astype(np.float64) - mu) * rs
     assert_close(ps[0], ref.sum(0), rtol=TOL, what="sum G", floor=np.abs(ref).sum(0).max() * 1e-6)
     assert_close(ps[1], (ref * xhat).sum(0), rtol=TOL, what="sum G xhat", floor=np.abs(ref * xhat).sum(0).max() * 1e-6)
+
+
+@pytest.mark.parametrize("N,K,want_dx", [(1, 7, True), (100, 7, True), (4096 + 33, 7, True), (40000 + 5, 3, True), (5000, 16, False)])
+def test_narrow_linear_backward_recomputing_its_output(N, K, want_dx):
+    """gnm_linear_bwd_fused_rz for a narrow input (K <= 16, the input layer's first Linear): against fp64 and against
+    gnm_linear_bwd_fused fed the Z that gnm_linear_fwd wrote; wider narrow inputs are declined"""
+    from gnm import core
+    from gnm._cabi import check, lib
+    H = 64
+    rng = np.random.default_rng(N + K)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(DEV)
+    X = (rng.standard_normal((N, K)) * 1.5 + 0.3).astype(np.float32)
+    W = (rng.standard_normal((H, K)) / 3).astype(np.float32)
+    b = rng.standard_normal(H).astype(np.float32)
+    G = rng.standard_normal((N, H)).astype(np.float32)
+    mean, rstd, cA, m1, m2 = (rng.uniform(0.5, 1.5, H).astype(np.float32) for _ in range(5))
+    Xd, Wd, bd, Gd = map(t, (X, W, b, G))
+    vec = [t(v) for v in (mean, rstd, cA, m1, m2)]
+    Z = torch.empty(N, H, device=DEV)
+    core._linear(Xd, Wd, 0, bd, Z, N, K, H, None, None)
+    assert lib.gnm_linear_bwd_fused_rz(Gd.data_ptr(), H, bd.data_ptr(), *[v.data_ptr() for v in vec], Xd.data_ptr(), 31, None, None,
+                                       0, Wd.data_ptr(), 31, None, 0, None, 0, None, None, N, 31, H, None, 0, None, None, None,
+                                       None, None, _stream()) == -2          # K = 31: two steps of Z, not this kernel's
+    out = []
+    for rz in (True, False):
+        dA = torch.full((N, K), float("nan"), device=DEV) if want_dx else None
+        dW = torch.full((H, K), float("nan"), device=DEV)
+        db = torch.full((H,), float("nan"), device=DEV)
+        ws = torch.empty(int(lib.gnm_linear_bwd_workspace_floats(N, H, K)), device=DEV)
+        tail = (Xd.data_ptr(), K, None, None, 0, Wd.data_ptr(), K, dA.data_ptr() if want_dx else None, K if want_dx else 0,
+                dW.data_ptr(), K, db.data_ptr(), ws.data_ptr(), N, K, H, None, 0, None, None, None, None, None, _stream())
+        if rz:
+            check(lib.gnm_linear_bwd_fused_rz(Gd.data_ptr(), H, bd.data_ptr(), *[v.data_ptr() for v in vec], *tail), "rz")
+        else:
+            check(lib.gnm_linear_bwd_fused(Gd.data_ptr(), H, Z.data_ptr(), H, *[v.data_ptr() for v in vec], *tail), "fused")
+        out.append([a.cpu().numpy() if a is not None else None for a in (dA, dW, db)])
+    X64 = X.astype(np.float64)
+    Z64 = X64 @ W.astype(np.float64).T + b
+    dZ = cA * (G - m1 - (Z64 - mean) * rstd * m2)
+    for name, (dA, dW, db) in zip(("rz", "stored Z"), out):
+        if want_dx:
+            assert_close(dA, dZ @ W.astype(np.float64), rtol=TOL, what=name + " dX")
+        assert_close(dW, dZ.T @ X64, rtol=TOL, what=name + " dW")
+        assert_close(db, dZ.sum(0), rtol=TOL, what=name + " db")
