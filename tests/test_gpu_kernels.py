@@ -482,7 +482,7 @@ from gnm import core
 from gnm._cabi import check, lib
 DEV = torch.device("cuda:0")
 K = H = 64
-for N, samez in [(n, z) for n in (1, 31, 4096 + 77, 40000 + 5) for z in (0, 1)]:
+for N, samez in [(n, z) for n in (1, 31, 4096 + 77, 40000 + 5) for z in (0, 1)] + [(409600, 0)]:     # (+ BASELINE's full size)
   rng = np.random.default_rng(N + samez)
   t = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).to(DEV)
   X = (rng.standard_normal((N, K)) * 1.5 + 0.3).astype(np.float32)
