@@ -8,11 +8,14 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-KERNELS = ["gnm_lin_split_kernel<2>", "gnm_lin_stream_kernel<64, 2>", "gnm_linear_bwd_pipe_kernel<2, 2, true>",
+KERNELS = ["gnm_lin_split_kernel<2>", "gnm_linear_bwd_rz_kernel<false, true>", "gnm_linear_bwd_rzn_kernel",
+           "gnm_linear_bwd_rz_kernel<true, true>", "gnm_lin_split128_kernel<false>", "gnm_lin_split128_kernel<true>",
+           "gnm_wgrad_split128_kernel", "gnm_small_gemm_kernel",
+           "gnm_lin_stream_kernel<64, 2>", "gnm_linear_bwd_pipe_kernel<2, 2, true>",
            "gnm_linear_bwd_pipe_kernel<2, 2, false>", "gnm_linear_bwd_fused_kernel<2, 2, true, false, true, true>",
            "gnm_linear_bwd_fused_kernel<2, 2, true, false, true, false>",
            "gnm_aggm_kernel<false, false, false>", "gnm_aggm_kernel<true, false, false>", "gnm_aggm_kernel<false, false, true>",
-           "gnm_disc_score_kernel<16>", "gnm_disc_du_kernel"]
+           "gnm_disc_score_kernel<16", "gnm_disc_du_kernel"]
 vals = {}
 for f in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")):
     for row in csv.DictReader(open(f)):
