@@ -54,14 +54,22 @@ struct LinArgs {
 // (one wave of every group of every workgroup first, on different SIMDs, then the next ...) every CU gets 50.
 // `groups` groups of four waves per workgroup, `rows` groups in the launch; a launch whose last workgroup is not full
 // (rows != groups * gridDim.x: small N) keeps the plain numbering, and waves past the last row get no tile.
-__device__ __forceinline__ int lin_first_tile(int wave, int groups, int rows) {
-    const int grp = wave >> 2, nwg = (int)gridDim.x, b = (int)blockIdx.x;
+__host__ __device__ __forceinline__ int lin_first_tile_of(int wave, int groups, int rows, int nwg, int b) {
+    const int grp = wave >> 2;
     if (rows == groups * nwg) {
         const int slot = ((wave & 3) + grp * (groups == 2 ? 2 : 1)) & 3;
         return (slot * groups + grp) * nwg + b;
     }
     const int gw = b * groups * 4 + wave;
     return gw < 4 * rows ? gw : 0x3fffffff;
+}
+__device__ __forceinline__ int lin_first_tile(int wave, int groups, int rows) {
+    return lin_first_tile_of(wave, groups, rows, (int)gridDim.x, (int)blockIdx.x);
+}
+// The same map on the host, for tests/test_host_logic.py: every tile index below 4 x rows must belong to exactly one
+// (workgroup, wave) of the launch, whatever the launch shape.
+extern "C" int gnm_debug_lin_first_tile(int wave, int groups, int rows, int nwg, int b) {
+    return lin_first_tile_of(wave, groups, rows, nwg, b);
 }
 
 #ifdef GNM_LIN_TUNING

@@ -58,6 +58,7 @@ SIGNATURES = {
     "gnm_linear_bwd_fused_rz": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p,
                                      _p, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
     "gnm_linear_dgrad_masked": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p]),
+    "gnm_debug_lin_first_tile": (_i, [_i, _i, _i, _i, _i]),
     "gnm_small_gemm": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "gnm_reduce_partials_multi": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "gnm_bn_finalize": (_i, [_p, _i, _i, _ll, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p]),

@@ -166,6 +166,10 @@ int gnm_sum_partials_multi(const double* partial, long long stride, const int* c
  * stats_partial (optional): [gnm_linear_grid(N)][2][H] doubles, per-column sum and sum
  * of squares of Z for the BatchNorm that follows.  H <= 128 per call. */
 int gnm_linear_grid(int N);
+/* Test hook (host arithmetic only): the first 32-row tile of wave `wave` of workgroup `b` in a launch of `nwg` workgroups
+ * with `groups` groups of four waves each and `rows` groups in total -- the tile -> wave map of every tile-strided Linear
+ * kernel (stride 4 x rows).  tests/test_host_logic.py checks that it is a bijection for every launch shape. */
+int gnm_debug_lin_first_tile(int wave, int groups, int rows, int nwg, int b);
 /* Largest input width K gnm_linear_fwd accepts for output width H (0: H unsupported; H <= 128).  The weight
  * stays LDS-resident, so K is bounded: 448 at H = 64, 192 at H = 128. */
 int gnm_linear_max_k(int H);

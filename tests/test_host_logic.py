@@ -255,3 +255,28 @@ def test_allreduce_gradients_is_a_mean_and_a_noop_for_one_rank():
     lin.weight.grad = None
     assert dp.allreduce_gradients() is None and dp.world == 1
     assert lin.weight.grad is not None and float(lin.weight.grad.sum()) == 12.0
+
+
+def test_tile_to_wave_map_of_the_linear_kernels_is_a_bijection():
+    """csrc/linear.hip lin_first_tile (balanced numbering of the waves that walk the 32-row tiles with a stride of all
+    active waves): for every launch shape each index below 4 x rows belongs to exactly one (workgroup, wave) -- a tile
+    nobody takes would be a block of rows left unwritten, a tile taken twice a data race -- and on full launches the first
+    `nwg` indices fall on `nwg` different workgroups (what the numbering is for)."""
+    from gnm._cabi import lib
+    f = lib.gnm_debug_lin_first_tile
+    for groups in (1, 2, 3):
+        for rows in list(range(1, 14)) + [255, 256, 512, 767, 768]:
+            nwg = (rows + groups - 1) // groups
+            seen = {}
+            for b in range(nwg):
+                for wave in range(4 * groups):
+                    t = f(wave, groups, rows, nwg, b)
+                    active = (b * groups + wave // 4) < rows
+                    if not active:
+                        assert t >= 4 * rows, (groups, rows, b, wave, t)      # takes no tile
+                        continue
+                    assert 0 <= t < 4 * rows and t not in seen, (groups, rows, b, wave, t, seen.get(t))
+                    seen[t] = (b, wave)
+            assert len(seen) == 4 * rows
+            if rows == groups * nwg and nwg > 1:
+                assert len({seen[t][0] for t in range(nwg)}) == nwg
