@@ -33,6 +33,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 
 #ifndef GNM_AGGM_WAVES
 #define GNM_AGGM_WAVES 8
@@ -118,18 +119,27 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     // and half the registers of the interleaved layout (which every lane had to load whole).
     const int HPW = (((W + 1) >> 1) + 3) & ~3;                   // words per half row (4 or 8)
     unsigned pkA[8], pkB[8];
+    // (1 + eps): requested first and consumed in the epilogue.  Unconditional (an absent eps reads a valid address and
+    // is dropped): a load inside a branch is drained right there, and until round 4 this one sat behind the barrier
+    // with its own vmcnt(0) -- an L2 round trip on every workgroup's critical path.
+    const float eps_raw = *(p.eps ? p.eps : p.x);
     {
+        // Both 16-byte pieces of a half row are requested unconditionally as well (HPW = 4, i.e. n <= 256: the first
+        // piece again; steps >= 16 that would use it do not exist).  The conditional second piece compiled to
+        // "load; s_waitcnt vmcnt(0)" AHEAD of the tile loads: every workgroup began by sitting out a memory round trip.
         const uint32_t* gbits = p.adj_bits + p.b_bits_off[b];
+        const int second = HPW > 4 ? 1 : 0;
         const u32x4* ra = reinterpret_cast<const u32x4*>(gbits + (size_t)(min(rbA, W - 1) * 32 + i) * (2 * HPW) + h * HPW);
         const u32x4* rb = reinterpret_cast<const u32x4*>(gbits + (size_t)((two ? rbB : min(rbA, W - 1)) * 32 + i) * (2 * HPW) + h * HPW);
-        const u32x4 z4 = {0u, 0u, 0u, 0u};
+        // (12 bytes of the second piece: its last word would be steps 28-31, which no graph of <= 416 nodes has -- and a
+        //  loaded register the compiler knows to be dead is reused at once, behind a vmcnt(0) for the write-after-write)
         const u32x4 a0 = ra[0], b0 = rb[0];
-        const u32x4 a1 = HPW > 4 ? ra[1] : z4, b1 = HPW > 4 ? rb[1] : z4;
+        const u32x3 a1 = *reinterpret_cast<const u32x3*>(ra + second), b1 = *reinterpret_cast<const u32x3*>(rb + second);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pkA[j] = a0[j]; pkA[4 + j] = a1[j];
-            pkB[j] = b0[j]; pkB[4 + j] = b1[j];
-        }
+        for (int j = 0; j < 4; ++j) { pkA[j] = a0[j]; pkB[j] = b0[j]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pkA[4 + j] = a1[j]; pkB[4 + j] = b1[j]; }
+        pkA[7] = 0u; pkB[7] = 0u;
     }
     if (tid < 16) {          // nibble e -> bf16 (bit 0, bit 1, bit 2, bit 3) as two words
         const unsigned one = 0x3F80u;
@@ -261,7 +271,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     }
 
     // ---- phase B ------------------------------------------------------------------------------
-    const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + *p.eps : 1.f);
+    const float selfB = p.self_loop ? 0.f : (p.eps ? 1.f + eps_raw : 1.f);
     const bool need_deg = AVG && !p.backward;
     const int col = col0 + i;
     float lsc = 0.f, lsh = 0.f, lmu = 0.f, s_pb = 0.f, s_ub = 0.f;
@@ -364,6 +374,22 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
             float ex[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) ex[q] = 0.f;
+            // The tile's own values of this lane's four elements, as phase A formed them (the three planes add up to
+            // them exactly): rows 8 k' + 4 h .. + 3 of one column are 8 contiguous bytes of a plane's k-group, so ONE
+            // ds_read_b64 per plane brings all four (round 4; until then twelve 2-byte reads per quarter, whose 16-byte
+            // lane stride put four lanes on every bank: all of the kernel's SQ_LDS_BANK_CONFLICT and half of its
+            // LDS-array cycles)
+            float wq[4];
+            {
+                const char* e = smem + (unsigned)min(rb * 4 + k, (n16 >> 3) - 1) * kAggmK8Stride + i * 16 + h * 8;
+                const u32x2 p1 = *reinterpret_cast<const u32x2*>(e);
+                const u32x2 p2 = *reinterpret_cast<const u32x2*>(e + plane_bytes);
+                const u32x2 p3 = *reinterpret_cast<const u32x2*>(e + 2u * plane_bytes);
+                wq[0] = (__uint_as_float(p1.x << 16) + __uint_as_float(p2.x << 16)) + __uint_as_float(p3.x << 16);
+                wq[1] = (__uint_as_float(p1.x & 0xFFFF0000u) + __uint_as_float(p2.x & 0xFFFF0000u)) + __uint_as_float(p3.x & 0xFFFF0000u);
+                wq[2] = (__uint_as_float(p1.y << 16) + __uint_as_float(p2.y << 16)) + __uint_as_float(p3.y << 16);
+                wq[3] = (__uint_as_float(p1.y & 0xFFFF0000u) + __uint_as_float(p2.y & 0xFFFF0000u)) + __uint_as_float(p3.y & 0xFFFF0000u);
+            }
             if constexpr (STATS) {
                 if (shuffled) {        // workgroup-uniform and rare (the workgroups of the first B rows of the batch)
                     int gq[4];
@@ -380,12 +406,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
             for (int q = 0; q < 4; ++q) {
                 const int vrow = vrow_of(rb, k, q);
                 float tot = acc[4 * k + q];
-                // the tile's own value of this element, as phase A formed it: the three planes add up to it exactly
-                const char* e = smem + (unsigned)(min(vrow, n16 - 1) >> 3) * kAggmK8Stride + i * 16 + (vrow & 7) * 2;
-                const float e1 = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(e) << 16);
-                const float e2 = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(e + plane_bytes) << 16);
-                const float e3 = __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(e + 2u * plane_bytes) << 16);
-                const float wv = (e1 + e2) + e3;
+                const float wv = wq[q];
                 if (p.self_loop) tot += wv;
                 if constexpr (AVG) {
                     if (need_deg) tot /= (float)(o.d1[q] - o.d0[q] + p.self_loop);      // 0/0 -> NaN as in the reference
@@ -406,6 +427,9 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                 }
                 // (row offset in the vector operand, scalar offset 0: see linear.hip, gnm_lin_stream_kernel)
                 // (NARROW: a lane whose column is past F stores to an offset the descriptor clips)
+                // (16-byte stores after a 4 x 4 DPP transpose inside lane quads -- 4 instead of 16 store instructions
+                //  per row block -- were measured in round 4: +7 us per launch, the 16 extra VALU per quarter cost more
+                //  than the store issue they save)
                 const unsigned yoff = (NARROW && col >= p.F) ? 0xFFFFFFF0u : (unsigned)((vrow * p.ldy + col) * 4);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ry, yoff, 0, 0);
             }
@@ -415,6 +439,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         GNM_MSTAMP(3)
         if (two) product(std::true_type{});
         else product(std::false_type{});
+        // (s_setprio 2 around the product: +1 us, round 4)
         GNM_MSTAMP(4)
         request(rbA, 1, ob);
         finish(rbA, 0, accA, oa);

@@ -74,11 +74,30 @@ def corr_graph(seed, n, t, f0, keep_pct=30.0):
     return und, feats, label
 
 
-def make_batch(base_seed, B, n, t, f0, isolate=None):
-    """isolate = (graph, node): that node loses all its edges (a row of padding only in the "max" pooling list)"""
+def knn_graph(seed, n, k, f0):
+    """SURVEY 8(d) sparse generator (BASELINE configs[3]): n points in 8 dimensions, each node's k nearest by squared
+    L2 distance, symmetrised by union (reference graphs are always symmetric: util.py:99-100)."""
+    rng = np.random.default_rng(seed)
+    P = rng.standard_normal((n, 8))
+    d2 = ((P[:, None, :] - P[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)
+    nn = np.argsort(d2, axis=1, kind="stable")[:, :k]
+    A = np.zeros((n, n), dtype=bool)
+    A[np.repeat(np.arange(n), k), nn.ravel()] = True
+    A |= A.T
+    iu, ju = np.nonzero(np.triu(A, 1))
+    und = np.stack([iu, ju], 1)
+    feats = rng.standard_normal((n, f0)).astype(np.float32)
+    label = int(rng.integers(0, 2))
+    return und, feats, label
+
+
+def make_batch(base_seed, B, n, t, f0, isolate=None, knn=None):
+    """isolate = (graph, node): that node loses all its edges (a row of padding only in the "max" pooling list);
+    knn = k: k-nearest-neighbour graphs (knn_graph) instead of thresholded correlations"""
     graphs, raw = [], []
     for g in range(B):
-        und, feats, label = corr_graph(base_seed + g, n, t, f0)
+        und, feats, label = knn_graph(base_seed + g, n, knn, f0) if knn else corr_graph(base_seed + g, n, t, f0)
         if isolate is not None and isolate[0] == g:
             und = und[(und != isolate[1]).all(1)]
         graphs.append(SynthGraph(n, und, feats, label))
@@ -103,10 +122,13 @@ def build_model(seed, L, m, f0, H, C, dropout, learn_eps, gpool, npool):
 
 
 def run_case(tag, model_seed, graph_seed, B, n, t, L, m, f0, H, C, learn_eps, gpool, npool,
-             state_file, row_stride=1, full_disc_grad=True, isolate=None):
+             state_file, row_stride=1, full_disc_grad=True, isolate=None, knn=None, no_isolated=False):
     if ONLY is not None and not tag.startswith(ONLY):
         return
-    graphs, raw = make_batch(graph_seed, B, n, t, f0, isolate)
+    graphs, raw = make_batch(graph_seed, B, n, t, f0, isolate, knn)
+    if no_isolated:      # neighbour "average" + learn_eps divides by the degree (graphcnn.py:157-158): keep 0/0 out
+        for gr in graphs:
+            assert min(len(x) for x in gr.neighbors) > 0, "%s: a node without neighbours; pick another graph seed" % tag
     out = {}
     out["cfg"] = np.array([L, m, f0, H, C, int(learn_eps), B, n], dtype=np.int64)
     out["gpool"] = np.array(gpool)
@@ -281,6 +303,29 @@ def main():
              learn_eps=True, gpool="average", npool="average", state_file=s0, row_stride=16, full_disc_grad=False)
     run_case("true_s0_eps0_gaverage_nsum", 0, 1000, B=2, n=400, t=256, L=5, m=2, f0=7, H=64, C=2,
              learn_eps=False, gpool="average", npool="sum", state_file=s0, row_stride=16, full_disc_grad=False)
+    # round 4 -- more graphs than nodes per graph (B > n): the Infomax "shuffle" n_f[idx, :] (graphcnn.py:198-201,
+    # 241-242) indexes ROWS 0 .. B-1 of the node matrix with graph numbers, so with B > n those rows leave graph 0 (the
+    # regime BASELINE configs[1] runs: B = 1024 > n = 400; every case above has B < n).  B a multiple of n and not.
+    run_case("tiny_s1_bgn_eps1_gsum_nsum", 1, 1300, B=12, n=8, t=16, L=3, m=2, f0=5, H=32, C=2,
+             learn_eps=True, gpool="sum", npool="sum", state_file=s1)
+    run_case("tiny_s1_bgn_eps0_gaverage_naverage", 1, 1300, B=16, n=8, t=16, L=3, m=2, f0=5, H=32, C=2,
+             learn_eps=False, gpool="average", npool="average", state_file=s1)
+    # ... at the headline widths (H = 64, five layers: the fused statistics kernels carry this branch), rows 0 .. 23
+    # span graphs 0, 1 and part of 2
+    run_case("tiny_s0_bgn_eps1_gsum_nsum", 0, 1400, B=24, n=10, t=24, L=5, m=2, f0=7, H=64, C=2,
+             learn_eps=True, gpool="sum", npool="sum", state_file=s0, row_stride=3, full_disc_grad=False)
+    run_case("tiny_s0_bgn_eps1_gaverage_naverage", 0, 1400, B=24, n=10, t=24, L=5, m=2, f0=7, H=64, C=2,
+             learn_eps=True, gpool="average", npool="average", state_file=s0, row_stride=3, full_disc_grad=False,
+             no_isolated=True)
+    # round 4 -- BASELINE configs[3]'s shape: 1000-node kNN (k = 20, symmetrised by union) graphs, H = 128, five layers
+    # (SURVEY 8(d) "Sparse synthetic"); per-node arrays row-subsampled.  Both aggregation forms: next_layer_eps with sum
+    # pooling, and the self-loop form next_layer with average neighbour pooling and average readout.
+    s4 = os.path.join(HERE, "state_seed4.npz")
+    run_case("true_c4_s4_eps1_gsum_nsum", 4, 2000, B=2, n=1000, t=0, L=5, m=2, f0=7, H=128, C=2,
+             learn_eps=True, gpool="sum", npool="sum", state_file=s4, row_stride=16, full_disc_grad=False, knn=20)
+    run_case("true_c4_s4_eps0_gaverage_naverage", 4, 2000, B=2, n=1000, t=0, L=5, m=2, f0=7, H=128, C=2,
+             learn_eps=False, gpool="average", npool="average", state_file=s4, row_stride=16, full_disc_grad=False,
+             knn=20)
 
 
 if __name__ == "__main__":
