@@ -41,7 +41,8 @@ typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 static constexpr int kAggmWaves = GNM_AGGM_WAVES;   // row blocks w and w + kAggmWaves per wave (13 blocks at n = 400)
 static constexpr int kAggmThreads = 64 * kAggmWaves;
 static constexpr int kAggmMaxN = 416;            // 13 row blocks; up to 400 nodes two workgroups share a CU's LDS
-static constexpr int kAggmScratch = 128 + 1024;  // nibble table + readout partials
+// nibble table + (forward prologue forms) readout partials / (statistics form) the graph's per-row discriminator gradient
+static constexpr int kAggmScratch = 128 + 4 * kAggmMaxN;
 // plane layout: [k / 8][32 columns][8 consecutive k] bf16, 528 bytes per k-group (512 + 16 of padding: the 8-byte
 // transposing writes of phase A then spread over all banks; the 16-byte reads of phase B are lane-linear either way)
 static constexpr unsigned kAggmK8Stride = 528;
@@ -100,6 +101,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     const unsigned plane_bytes = (unsigned)(p.n16_max >> 3) * kAggmK8Stride;
     char* lut = smem + 3u * plane_bytes;
     float4* rsum = reinterpret_cast<float4*>(lut + 128);
+    float* dvs = reinterpret_cast<float*>(lut + 128);          // STATS only (rsum is the forward prologue's)
     const bool prescale = AVG && p.backward;
     const bool pro = !STATS && p.p_scale != nullptr;
     const bool dot_a = p.deps_partial && p.hfwd;
@@ -147,6 +149,12 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         v.x = ((tid & 1) ? one : 0u) | ((tid & 2) ? one << 16 : 0u);
         v.y = ((tid & 4) ? one : 0u) | ((tid & 8) ? one << 16 : 0u);
         *reinterpret_cast<u32x2*>(lut + 8 * tid) = v;
+    }
+
+    // Statistics form: the per-row gradient of the discriminator's first score (one float per node) goes to LDS here,
+    // one coalesced load, instead of sixteen 4-byte global loads per row block and lane in the epilogue.
+    if constexpr (STATS) {
+        if (p.s_dsc1 && tid < n) dvs[tid] = p.s_dsc1[row0 + tid];
     }
 
     // ---- phase A ------------------------------------------------------------------------------
@@ -347,14 +355,13 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         const bool need_xs = prescale && !p.self_loop;      // the (1 + eps) self term of the "average" backward: raw input
         const bool shuffled = STATS && p.s_dsc1 && row0 < p.n_batch;   // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
         const bool has_dsc = STATS && p.s_dsc1 != nullptr;
-        const float* dscp = has_dsc ? p.s_dsc1 : p.x;       // absent: any readable address, value discarded
         const bool want_dot = STATS && p.deps_partial && !p.hfwd && !p.self_loop;
         const unsigned ybytes = (unsigned)(((size_t)(n - 1) * p.ldy + p.F) * 4);
         const __amdgpu_buffer_rsrc_t ry =
             __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)row0 * p.ldy, 0, (int)ybytes, 0x00020000);
         // quarter blocks: 4 rows per lane at a time (r = 4 k + q: rows rb * 32 + 8 k + 4 h + q); two quarters' operands
         // are in flight (with 8-row halves the two operand sets spilled at 128 registers)
-        struct Ops { float zr[4], dv[4], xs[4]; int d0[4], d1[4]; };
+        struct Ops { float zr[4], xs[4]; int d0[4], d1[4]; };
         auto vrow_of = [&](int rb, int k, int q) { return rb * 32 + 8 * k + 4 * h + q; };
         auto request = [&](int rb, int k, Ops& o) {
 #pragma unroll
@@ -362,7 +369,6 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                 const int vc = min(vrow_of(rb, k, q), n - 1);
                 if constexpr (STATS) {
                     o.zr[q] = p.sZ[(size_t)(row0 + vc) * p.ldsz + col];
-                    o.dv[q] = dscp[row0 + vc];
                 }
                 if constexpr (AVG) {
                     o.xs[q] = p.x[(size_t)(row0 + vc) * p.ldx + (NARROW ? min(col, p.F - 1) : col)];
@@ -379,6 +385,8 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
             // ds_read_b64 per plane brings all four (round 4; until then twelve 2-byte reads per quarter, whose 16-byte
             // lane stride put four lanes on every bank: all of the kernel's SQ_LDS_BANK_CONFLICT and half of its
             // LDS-array cycles)
+            f32x4 dv4 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (STATS) dv4 = *reinterpret_cast<const f32x4*>(dvs + rb * 32 + 8 * k + 4 * h);   // (rows >= n: unused)
             float wq[4];
             {
                 const char* e = smem + (unsigned)min(rb * 4 + k, (n16 >> 3) - 1) * kAggmK8Stride + i * 16 + h * 8;
@@ -417,7 +425,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                 if constexpr (STATS) {
                     const float zrow = o.zr[q];
                     if (want_dot && vrow < n) dot += (double)(sb * gnm_relu(zrow * lsc + lsh));   // h as the forward formed it
-                    tot += s_pb + (has_dsc ? o.dv[q] : 0.f) * s_ub;
+                    tot += s_pb + (has_dsc ? dv4[q] : 0.f) * s_ub;
                     tot += ex[q];
                     if (!(zrow * lsc + lsh > 0.f)) tot = 0.f;
                     if (vrow < n) {
