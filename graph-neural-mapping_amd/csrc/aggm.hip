@@ -151,11 +151,11 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         *reinterpret_cast<u32x2*>(lut + 8 * tid) = v;
     }
 
-    // Statistics form: the per-row gradient of the discriminator's first score (one float per node) goes to LDS here,
-    // one coalesced load, instead of sixteen 4-byte global loads per row block and lane in the epilogue.
-    if constexpr (STATS) {
-        if (p.s_dsc1 && tid < n) dvs[tid] = p.s_dsc1[row0 + tid];
-    }
+    // Statistics form: the per-row gradient of the discriminator's first score (one float per node) goes to LDS, one
+    // coalesced load, instead of sixteen 4-byte global loads per row block and lane in the epilogue.  Requested here,
+    // unconditionally (absent: any readable address); written to LDS behind the tile (a write here would wait for it).
+    float dv_early = 0.f;
+    if constexpr (STATS) dv_early = (p.s_dsc1 ? p.s_dsc1 : p.x)[row0 + min(tid, n - 1)];
 
     // ---- phase A ------------------------------------------------------------------------------
     // item = (4 consecutive rows, 4 consecutive columns): four 16-B loads, transposed in registers into 8-B pieces
@@ -263,6 +263,9 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         }
         if (rql == 0) rsum[wave * 8 + c4] = csum;
     }
+    if constexpr (STATS) {      // (zeros where there is nothing: the epilogue multiplies without asking)
+        if (tid < kAggmMaxN) dvs[tid] = (p.s_dsc1 && tid < n) ? dv_early : 0.f;
+    }
     GNM_MSTAMP(2)
     __syncthreads();
     if (pro && p.p_gf && tid < 8) {
@@ -356,6 +359,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         const bool shuffled = STATS && p.s_dsc1 && row0 < p.n_batch;   // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
         const bool has_dsc = STATS && p.s_dsc1 != nullptr;
         const bool want_dot = STATS && p.deps_partial && !p.hfwd && !p.self_loop;
+        const float cself = p.self_loop ? 1.f : selfB;
         const unsigned ybytes = (unsigned)(((size_t)(n - 1) * p.ldy + p.F) * 4);
         const __amdgpu_buffer_rsrc_t ry =
             __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)row0 * p.ldy, 0, (int)ybytes, 0x00020000);
@@ -363,16 +367,28 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
         // are in flight (with 8-row halves the two operand sets spilled at 128 registers)
         struct Ops { float zr[4], xs[4]; int d0[4], d1[4]; };
         auto vrow_of = [&](int rb, int k, int q) { return rb * 32 + 8 * k + 4 * h + q; };
+        // Addresses of a quarter's four elements (round 4): byte offset of the lane's element of row 4 h in block row 0
+        // (computed once) + a wave-uniform quarter offset + q row strides -- one VALU add per access instead of a
+        // clamp, a 64-bit multiply-add and a shift; rows past n are clipped by the buffer descriptors (loads return 0,
+        // stores are dropped), a NARROW lane past F sits 2 GiB out.
+        const unsigned row_y = (unsigned)p.ldy * 4u;
+        const unsigned lane_y = (NARROW && col >= p.F) ? 0x80000000u : (unsigned)((4 * h * p.ldy + col) * 4);
+        const unsigned row_z = STATS ? (unsigned)p.ldsz * 4u : 0u;
+        const unsigned lane_z = STATS ? (unsigned)((4 * h * p.ldsz + col) * 4) : 0u;
+        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(STATS ? p.sZ + (size_t)row0 * p.ldsz : p.x), 0,
+            STATS ? (int)(((size_t)(n - 1) * p.ldsz + p.F) * 4) : 0, 0x00020000);
         auto request = [&](int rb, int k, Ops& o) {
+            const unsigned zq = lane_z + (unsigned)(rb * 32 + 8 * k) * row_z;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int vc = min(vrow_of(rb, k, q), n - 1);
                 if constexpr (STATS) {
-                    o.zr[q] = p.sZ[(size_t)(row0 + vc) * p.ldsz + col];
+                    o.zr[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rz, zq + q * row_z, 0, 0));
                 }
                 if constexpr (AVG) {
                     o.xs[q] = p.x[(size_t)(row0 + vc) * p.ldx + (NARROW ? min(col, p.F - 1) : col)];
-                    o.d0[q] = frp[vc]; o.d1[q] = frp[vc + 1];
+                    if constexpr (!STATS) { o.d0[q] = frp[vc]; o.d1[q] = frp[vc + 1]; }   // (forward only: the degree division)
                 }
             }
         };
@@ -387,6 +403,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
             // LDS-array cycles)
             f32x4 dv4 = {0.f, 0.f, 0.f, 0.f};
             if constexpr (STATS) dv4 = *reinterpret_cast<const f32x4*>(dvs + rb * 32 + 8 * k + 4 * h);   // (rows >= n: unused)
+            const unsigned yq = lane_y + (unsigned)(rb * 32 + 8 * k) * row_y;
             float wq[4];
             {
                 const char* e = smem + (unsigned)min(rb * 4 + k, (n16 >> 3) - 1) * kAggmK8Stride + i * 16 + h * 8;
@@ -410,36 +427,48 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                     }
                 }
             }
+            // (values of k-groups past the graph's last: the read above was clamped to a valid group -- drop them)
+            const bool in_tile = rb * 4 + k < (n16 >> 3);            // wave-uniform
+            float dq = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int vrow = vrow_of(rb, k, q);
-                float tot = acc[4 * k + q];
-                const float wv = wq[q];
-                if (p.self_loop) tot += wv;
-                if constexpr (AVG) {
-                    if (need_deg) tot /= (float)(o.d1[q] - o.d0[q] + p.self_loop);      // 0/0 -> NaN as in the reference
-                }
+                const float wv = in_tile ? wq[q] : 0.f;
+                float tot;
                 float sb = wv;
-                if constexpr (AVG) sb = need_xs ? o.xs[q] : wv;
-                if (!p.self_loop) tot += selfB * sb;
+                if constexpr (AVG) {
+                    tot = acc[4 * k + q];
+                    if (p.self_loop) tot += wv;
+                    if constexpr (!STATS) {
+                        if (need_deg) tot /= (float)(o.d1[q] - o.d0[q] + p.self_loop);  // 0/0 -> NaN as in the reference
+                    }
+                    sb = need_xs ? o.xs[q] : wv;
+                    if (!p.self_loop) tot += selfB * sb;
+                    if (vrow >= n) sb = 0.f;
+                } else {
+                    tot = fmaf(cself, wv, acc[4 * k + q]);       // self loop: + h; eps form: + (1 + eps) h
+                }
                 if constexpr (STATS) {
                     const float zrow = o.zr[q];
-                    if (want_dot && vrow < n) dot += (double)(sb * gnm_relu(zrow * lsc + lsh));   // h as the forward formed it
-                    tot += s_pb + (has_dsc ? dv4[q] : 0.f) * s_ub;
+                    const float pre = fmaf(zrow, lsc, lsh);
+                    dq = fmaf(sb, gnm_relu(pre), dq);              // h as the forward formed it (rows >= n: sb = 0)
+                    tot += s_pb + dv4[q] * s_ub;
                     tot += ex[q];
-                    if (!(zrow * lsc + lsh > 0.f)) tot = 0.f;
-                    if (vrow < n) {
-                        ss1 += tot;
-                        ss2 += tot * (zrow - lmu);
-                    }
+                    // the ReLU mask of the layer below; rows past n (their loads returned 0) count as masked, so the
+                    // column sums need no guard of their own (the store of such a row is clipped anyway)
+                    if (!(pre > 0.f && vrow < n)) tot = 0.f;
+                    ss1 += tot;
+                    ss2 = fmaf(tot, zrow - lmu, ss2);
                 }
                 // (row offset in the vector operand, scalar offset 0: see linear.hip, gnm_lin_stream_kernel)
                 // (NARROW: a lane whose column is past F stores to an offset the descriptor clips)
                 // (16-byte stores after a 4 x 4 DPP transpose inside lane quads -- 4 instead of 16 store instructions
                 //  per row block -- were measured in round 4: +7 us per launch, the 16 extra VALU per quarter cost more
                 //  than the store issue they save)
-                const unsigned yoff = (NARROW && col >= p.F) ? 0xFFFFFFF0u : (unsigned)((vrow * p.ldy + col) * 4);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ry, yoff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tot), ry, yq + q * row_y, 0, 0);
+            }
+            if constexpr (STATS) {
+                if (want_dot) dot += (double)dq;      // (four fp32 products summed in fp32, the partials in fp64)
             }
         };
         Ops oa, ob;
