@@ -92,12 +92,13 @@ def knn_graph(seed, n, k, f0):
     return und, feats, label
 
 
-def make_batch(base_seed, B, n, t, f0, isolate=None, knn=None):
+def make_batch(base_seed, B, n, t, f0, isolate=None, knn=None, keep_pct=30.0):
     """isolate = (graph, node): that node loses all its edges (a row of padding only in the "max" pooling list);
     knn = k: k-nearest-neighbour graphs (knn_graph) instead of thresholded correlations"""
     graphs, raw = [], []
     for g in range(B):
-        und, feats, label = knn_graph(base_seed + g, n, knn, f0) if knn else corr_graph(base_seed + g, n, t, f0)
+        und, feats, label = (knn_graph(base_seed + g, n, knn, f0) if knn else
+                             corr_graph(base_seed + g, n, t, f0, keep_pct))
         if isolate is not None and isolate[0] == g:
             und = und[(und != isolate[1]).all(1)]
         graphs.append(SynthGraph(n, und, feats, label))
@@ -122,10 +123,11 @@ def build_model(seed, L, m, f0, H, C, dropout, learn_eps, gpool, npool):
 
 
 def run_case(tag, model_seed, graph_seed, B, n, t, L, m, f0, H, C, learn_eps, gpool, npool,
-             state_file, row_stride=1, full_disc_grad=True, isolate=None, knn=None, no_isolated=False):
+             state_file, row_stride=1, full_disc_grad=True, isolate=None, knn=None, no_isolated=False,
+             keep_pct=30.0):
     if ONLY is not None and not tag.startswith(ONLY):
         return
-    graphs, raw = make_batch(graph_seed, B, n, t, f0, isolate, knn)
+    graphs, raw = make_batch(graph_seed, B, n, t, f0, isolate, knn, keep_pct)
     if no_isolated:      # neighbour "average" + learn_eps divides by the degree (graphcnn.py:157-158): keep 0/0 out
         for gr in graphs:
             assert min(len(x) for x in gr.neighbors) > 0, "%s: a node without neighbours; pick another graph seed" % tag
@@ -314,9 +316,9 @@ def main():
     # span graphs 0, 1 and part of 2
     run_case("tiny_s0_bgn_eps1_gsum_nsum", 0, 1400, B=24, n=10, t=24, L=5, m=2, f0=7, H=64, C=2,
              learn_eps=True, gpool="sum", npool="sum", state_file=s0, row_stride=3, full_disc_grad=False)
-    run_case("tiny_s0_bgn_eps1_gaverage_naverage", 0, 1400, B=24, n=10, t=24, L=5, m=2, f0=7, H=64, C=2,
+    run_case("tiny_s0_bgn_eps1_gaverage_naverage", 0, 1400, B=30, n=12, t=24, L=5, m=2, f0=7, H=64, C=2,
              learn_eps=True, gpool="average", npool="average", state_file=s0, row_stride=3, full_disc_grad=False,
-             no_isolated=True)
+             no_isolated=True, keep_pct=60.0)
     # round 4 -- BASELINE configs[3]'s shape: 1000-node kNN (k = 20, symmetrised by union) graphs, H = 128, five layers
     # (SURVEY 8(d) "Sparse synthetic"); per-node arrays row-subsampled.  Both aggregation forms: next_layer_eps with sum
     # pooling, and the self-loop form next_layer with average neighbour pooling and average readout.

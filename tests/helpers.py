@@ -130,6 +130,7 @@ class Calibrated:
         self.factor = factor
         self.noise = 0.0
         self.log = []          # (what, error of the checked value vs fp64, the reference's own error, bound applied)
+        self.log_golden = []   # error of the checked value vs the reference's golden directly (reported, not asserted)
 
     def check(self, a, golden, truth64, what="", floor=0.0):
         ref_noise = rel_err(golden, truth64, floor)
@@ -139,4 +140,5 @@ class Calibrated:
         e = rel_err(a, truth64, floor)
         assert e <= bound, f"{what}: err vs fp64 oracle {e:.3e} > {bound:.2e} (reference noise {self.noise:.2e})"
         self.log.append((what, e, ref_noise, bound))
+        self.log_golden.append(rel_err(a, golden, floor))
         return e
