@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // ---- which graph / column block: the blocks of one graph sit 8 apart, i.e. on the same XCD (one L2 serves the
     //      bit matrix and the tile to all of them)
+    GNM_MSTAMP(8)
     const int nc = NARROW ? 1 : p.F >> 5;                         // 32-column blocks per graph
     const int grp = blockIdx.x / (8 * nc), within = blockIdx.x - grp * (8 * nc);
     const int b = grp * 8 + (within & 7);
@@ -114,35 +115,6 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     const int rbA = role, rbB = role + kAggmWaves;
     const bool two = rbB < W;
     const bool has_rows = p.y && rbA < W;
-    // Bit rows (round 3 layout, see gnm_adj_bits_build): a row's bytes are stored de-interleaved -- the even bytes
-    // (columns 16 s .. 16 s + 7 of MFMA step s: what lanes 0-31 multiply) in the first half of the row, the odd bytes
-    // (columns 16 s + 8 .. + 15: lanes 32-63) in the second, each half padded to 16-byte pieces.  A lane therefore
-    // loads exactly the bytes it uses, byte m of word j = step 4 j + m, as one or two 16-byte pieces: no permutes
-    // and half the registers of the interleaved layout (which every lane had to load whole).
-    const int HPW = (((W + 1) >> 1) + 3) & ~3;                   // words per half row (4 or 8)
-    unsigned pkA[8], pkB[8];
-    // (1 + eps): requested first and consumed in the epilogue.  Unconditional (an absent eps reads a valid address and
-    // is dropped): a load inside a branch is drained right there, and until round 4 this one sat behind the barrier
-    // with its own vmcnt(0) -- an L2 round trip on every workgroup's critical path.
-    const float eps_raw = *(p.eps ? p.eps : p.x);
-    {
-        // Both 16-byte pieces of a half row are requested unconditionally as well (HPW = 4, i.e. n <= 256: the first
-        // piece again; steps >= 16 that would use it do not exist).  The conditional second piece compiled to
-        // "load; s_waitcnt vmcnt(0)" AHEAD of the tile loads: every workgroup began by sitting out a memory round trip.
-        const uint32_t* gbits = p.adj_bits + p.b_bits_off[b];
-        const int second = HPW > 4 ? 1 : 0;
-        const u32x4* ra = reinterpret_cast<const u32x4*>(gbits + (size_t)(min(rbA, W - 1) * 32 + i) * (2 * HPW) + h * HPW);
-        const u32x4* rb = reinterpret_cast<const u32x4*>(gbits + (size_t)((two ? rbB : min(rbA, W - 1)) * 32 + i) * (2 * HPW) + h * HPW);
-        // (12 bytes of the second piece: its last word would be steps 28-31, which no graph of <= 416 nodes has -- and a
-        //  loaded register the compiler knows to be dead is reused at once, behind a vmcnt(0) for the write-after-write)
-        const u32x4 a0 = ra[0], b0 = rb[0];
-        const u32x3 a1 = *reinterpret_cast<const u32x3*>(ra + second), b1 = *reinterpret_cast<const u32x3*>(rb + second);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { pkA[j] = a0[j]; pkB[j] = b0[j]; }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { pkA[4 + j] = a1[j]; pkB[4 + j] = b1[j]; }
-        pkA[7] = 0u; pkB[7] = 0u;
-    }
     if (tid < 16) {          // nibble e -> bf16 (bit 0, bit 1, bit 2, bit 3) as two words
         const unsigned one = 0x3F80u;
         u32x2 v;
@@ -192,6 +164,40 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
             }
         }
     }
+    // (round 4: requested BEHIND the tile loads.  Their address needs one more dependent scalar read -- the graph's
+    //  offset into the bit arena, ~1.8 us after the node offsets under load per the in-kernel timeline -- which now
+    //  passes while the tile is on its way from HBM; the bits themselves mostly come from L2)
+    __builtin_amdgcn_sched_barrier(0);          // (left alone, the scheduler hoists that scalar read and its wait above the tile loads)
+    // Bit rows (round 3 layout, see gnm_adj_bits_build): a row's bytes are stored de-interleaved -- the even bytes
+    // (columns 16 s .. 16 s + 7 of MFMA step s: what lanes 0-31 multiply) in the first half of the row, the odd bytes
+    // (columns 16 s + 8 .. + 15: lanes 32-63) in the second, each half padded to 16-byte pieces.  A lane therefore
+    // loads exactly the bytes it uses, byte m of word j = step 4 j + m, as one or two 16-byte pieces: no permutes
+    // and half the registers of the interleaved layout (which every lane had to load whole).
+    const int HPW = (((W + 1) >> 1) + 3) & ~3;                   // words per half row (4 or 8)
+    unsigned pkA[8], pkB[8];
+    // (1 + eps): requested first and consumed in the epilogue.  Unconditional (an absent eps reads a valid address and
+    // is dropped): a load inside a branch is drained right there, and until round 4 this one sat behind the barrier
+    // with its own vmcnt(0) -- an L2 round trip on every workgroup's critical path.
+    const float eps_raw = *(p.eps ? p.eps : p.x);
+    {
+        // Both 16-byte pieces of a half row are requested unconditionally as well (HPW = 4, i.e. n <= 256: the first
+        // piece again; steps >= 16 that would use it do not exist).  The conditional second piece compiled to
+        // "load; s_waitcnt vmcnt(0)" AHEAD of the tile loads: every workgroup began by sitting out a memory round trip.
+        const uint32_t* gbits = p.adj_bits + p.b_bits_off[b];
+        const int second = HPW > 4 ? 1 : 0;
+        const u32x4* ra = reinterpret_cast<const u32x4*>(gbits + (size_t)(min(rbA, W - 1) * 32 + i) * (2 * HPW) + h * HPW);
+        const u32x4* rb = reinterpret_cast<const u32x4*>(gbits + (size_t)((two ? rbB : min(rbA, W - 1)) * 32 + i) * (2 * HPW) + h * HPW);
+        // (12 bytes of the second piece: its last word would be steps 28-31, which no graph of <= 416 nodes has -- and a
+        //  loaded register the compiler knows to be dead is reused at once, behind a vmcnt(0) for the write-after-write)
+        const u32x4 a0 = ra[0], b0 = rb[0];
+        const u32x3 a1 = *reinterpret_cast<const u32x3*>(ra + second), b1 = *reinterpret_cast<const u32x3*>(rb + second);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pkA[j] = a0[j]; pkB[j] = b0[j]; }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pkA[4 + j] = a1[j]; pkB[4 + j] = b1[j]; }
+        pkA[7] = 0u; pkB[7] = 0u;
+    }
+    GNM_MSTAMP(7)
     GNM_MSTAMP(1)
 #pragma unroll
     for (int u = 0; u < UA; ++u) {

@@ -78,7 +78,7 @@ e0.record(); run(); e1.record(); torch.cuda.synchronize()
 lib.gnm_debug_set_aggm_stamps(None)
 ms = e0.elapsed_time(e1)
 s = stamps.cpu().numpy().reshape(WG, 8, 16).astype(np.float64)
-t0 = s[:, :, 0].min(1, keepdims=True)
+t0 = s[:, :, 8].min(1, keepdims=True)
 life = (s[:, :, 6].max(1, keepdims=True) - t0)
 print("%s: launch %.1f us (stamped build), %d workgroups of 8 waves; workgroup lifetime %0.f ticks (median)" %
       (args.mode, ms * 1e3, WG, np.median(life)))
@@ -92,6 +92,8 @@ for k, nm in enumerate(names):
     d = (s[:, :, k + 1] - s[:, :, k]) / life
     w = active if k >= 3 else np.ones_like(active)
     print("    %-52s %5.1f %% of the workgroup's lifetime (waves with work)" % (nm, 100 * d[w].mean()))
+print("    %-52s %5.1f %% / %5.1f %%" % ("  of which: entry -> graph descriptor read / -> bit rows requested",
+                                       100 * ((s[:, :, 0] - s[:, :, 8]) / life).mean(), 100 * ((s[:, :, 7] - s[:, :, 0]) / life).mean()))
 print("    %-52s %5.1f %%" % ("idle at the end (wave done, workgroup not)", 100 * ((s[:, :, 6].max(1, keepdims=True) - s[:, :, 6]) / life).mean()))
 two = (s[:, :, 6] - s[:, :, 5]) > 0.02 * life
 print("    waves with two row blocks: %.2f of 8; with none: %.2f" % (two.sum(1).mean(), (~active).sum(1).mean()))
