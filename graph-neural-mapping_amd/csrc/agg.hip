@@ -1275,7 +1275,7 @@ __global__ void __launch_bounds__(1024) gnm_agg16_kernel(const AggArgs p) {
                 tot.x += s_pb.x + dsc_v * s_ub.x; tot.y += s_pb.y + dsc_v * s_ub.y;
                 tot.z += s_pb.z + dsc_v * s_ub.z; tot.w += s_pb.w + dsc_v * s_ub.w;
                 if (p.s_dsc1 && row0 + v < p.n_batch) {     // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
-                    const int gq = min(max(p.s_inv_perm[row0 + v], 0), p.n_batch - 1);   // (never a wild address)
+                    const int gq = gnm_perm_entry(p.s_inv_perm[row0 + v], p.n_batch);
                     const float s2 = p.s_s2sum[gq];
                     const float4 uq = *reinterpret_cast<const float4*>(p.s_U + (size_t)gq * p.ld_U + 4 * sub);
                     tot.x += s2 * uq.x; tot.y += s2 * uq.y; tot.z += s2 * uq.z; tot.w += s2 * uq.w;

@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
                 if (shuffled) {        // workgroup-uniform and rare (the workgroups of the first B rows of the batch)
                     int gq[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) gq[q] = min(max(p.s_inv_perm[min(row0 + min(vrow_of(rb, k, q), n - 1), p.n_batch - 1)], 0), p.n_batch - 1);
+                    for (int q = 0; q < 4; ++q) gq[q] = gnm_perm_entry(p.s_inv_perm[min(row0 + min(vrow_of(rb, k, q), n - 1), p.n_batch - 1)], p.n_batch);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float t = p.s_s2sum[gq[q]] * p.s_U[(size_t)gq[q] * p.ld_U + col];

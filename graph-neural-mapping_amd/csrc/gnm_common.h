@@ -54,6 +54,19 @@ static constexpr int kLdsBudget = 160 * 1024;  // bytes of LDS per CU (gfx950)
 // One instruction on gfx950 (v_maximum3_f32, IEEE-754-2019 maximum).
 __device__ __forceinline__ float gnm_relu(float x) { return __builtin_elementwise_maximum(x, 0.f); }
 
+// An entry of the inverse Infomax permutation (graphcnn.py:198-201; scattered by the discriminator kernels from the
+// caller's permutation).  The HOST validates every permutation it uploads (gnm/core.py perm_to_device: a permutation
+// of 0 .. B-1 or GnmError), so the entry is used as it is; round 3's clamp into [0, B) -- which turned a bad
+// permutation into silently wrong gradients instead of a fault -- survives only for debugging builds.
+__device__ __forceinline__ int gnm_perm_entry(int v, int B) {
+#ifdef GNM_DEBUG_CLAMP_PERM
+    return min(max(v, 0), B - 1);
+#else
+    (void)B;
+    return v;
+#endif
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(1024) gnm_bn_relu_bwd_stats_kernel(
             if (dsc1) {
                 t.x += s * ub.x; t.y += s * ub.y; t.z += s * ub.z; t.w += s * ub.w;
                 if (v < B) {
-                    const int gq = min(max(inv_perm[v], 0), B - 1);      // (never a wild address)
+                    const int gq = gnm_perm_entry(inv_perm[v], B);
                     const float s2 = s2sum[gq];
                     const float4 uq = *reinterpret_cast<const float4*>(U + (size_t)gq * ldu + 4 * c4);
                     t.x += s2 * uq.x; t.y += s2 * uq.y; t.z += s2 * uq.z; t.w += s2 * uq.w;

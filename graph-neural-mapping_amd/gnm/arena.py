@@ -311,7 +311,7 @@ class GraphArena:
         """gids: int64 tensor (host or device) of arena ids."""
         tb = self._tables()
         gh = gids.cpu().numpy() if torch.is_tensor(gids) else np.asarray(gids, dtype=np.int64)
-        gd = torch.as_tensor(gh, dtype=torch.int64).to(self.device, non_blocking=True)
+        gd = self._upload(torch.as_tensor(gh, dtype=torch.int64))
         ns = tb["n_host"][gh]
         b = Batch()
         b.arena = self
@@ -323,7 +323,7 @@ class GraphArena:
         np.cumsum(ns, out=node_off_host[1:])
         b.node_off_host = node_off_host
         b.N = int(node_off_host[-1])
-        b.node_off = torch.as_tensor(node_off_host.astype(np.int32)).to(self.device, non_blocking=True)
+        b.node_off = self._upload(torch.as_tensor(node_off_host.astype(np.int32)))
         b.rp_off = tb["rp"][gd]
         b.col_off = tb["col"][gd]
         b.feat_base = tb["feat"][gd]
@@ -338,6 +338,14 @@ class GraphArena:
         b.bits_off = tb["bits"][gd]
         b.t_bits_off = b.bits_off if b.symmetric else tb["tbits"][gd]
         return b
+
+    def _upload(self, host):
+        """small host vector -> device without stalling the host: through pinned memory (torch's caching host allocator
+        keeps the block until the copy has run).  A pageable source makes the copy wait for everything queued on the
+        stream first -- with replayed steps in the queue that is a whole training step per batch assembled."""
+        if self.device.type == "cuda":
+            host = host.pin_memory()
+        return host.to(self.device, non_blocking=True)
 
     def dense_ok(self, gh):
         """do the graphs gh (host int64 array of arena ids) form a batch for the matrix-core aggregation?"""
@@ -453,6 +461,11 @@ class GraphArena:
         return out[:, :nnz]
 
 
+class BatchClassMismatch(ValueError):
+    """StaticBatch.load: the batch is of another class (size, symmetry, density route, isolated nodes) than the one the
+    buffers were captured for -- the one condition a replayed step answers by running eagerly (gnm/graphs.py)."""
+
+
 class StaticBatch:
     """A Batch whose device tensors keep their addresses: load(batch) copies another
     batch's descriptors into them.  What a captured hipGraph of the training step reads
@@ -486,7 +499,7 @@ class StaticBatch:
         b = self.batch
         if (other.B, other.N, other.n_max, other.n_min, other.symmetric, other.dense, other.iso) != \
                 (b.B, b.N, b.n_max, b.n_min, b.symmetric, b.dense, b.iso) or other.nnz_max > b.nnz_max:
-            raise ValueError("StaticBatch.load: batch shape differs from the captured one")
+            raise BatchClassMismatch("StaticBatch.load: batch shape differs from the captured one")
         if (self.extra is None) != (extra is None):
             raise ValueError("StaticBatch.load: `extra` must be given exactly when the buffer was built with extra_int64")
         if not np.array_equal(other.node_off_host, b.node_off_host):       # equal-size graphs: never changes

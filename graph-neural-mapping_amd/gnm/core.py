@@ -14,6 +14,8 @@ for the sum/average path: on a non-GPU tensor the calls raise.
 import ctypes as C
 import os
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -458,10 +460,10 @@ class DiscUnit:
     Any other loss (main.py's torch losses, explicit d_labels, a d_logit that also feeds something else so that
     autograd SUMS gradients into a new tensor) leaves k unset or the pointer different, and the backward runs
     gnm_disc_score_bwd exactly as before."""
-    __slots__ = ("unit", "inv_perm", "k", "kscale", "dD_ptr")
+    __slots__ = ("unit", "inv_perm", "k", "kscale", "dD_ptr", "dD_version")
 
     def __init__(self):
-        self.unit = self.inv_perm = self.k = self.dD_ptr = None
+        self.unit = self.inv_perm = self.k = self.dD_ptr = self.dD_version = None
         self.kscale = 1.0
 
 
@@ -543,6 +545,37 @@ def eval_fused_ok(spec, batch, X, P, mode=True):
     return H == 64 and 1 <= spec.m <= 3 and spec.L <= 16 and X.shape[1] <= 64 and C_ <= 64 and X.is_cuda
 
 
+def check_permutation(perm, B):
+    """The Infomax shuffle (graphcnn.py:199: np.random.permutation(B)) as a host int array, validated: the kernels
+    scatter its inverse and index rows with it unchecked, so anything that is not a permutation of 0 .. B-1 must stop
+    here (round 3 clamped on the device instead and would have trained on wrong gradients)."""
+    p = np.asarray(perm)
+    if p.ndim != 1 or p.shape[0] != B or p.dtype.kind not in "iu":
+        raise GnmError("perm must be %d integers (np.random.permutation(B), graphcnn.py:199); got shape %s dtype %s"
+                       % (B, p.shape, p.dtype))
+    if B and (int(p.min()) < 0 or int(p.max()) >= B or not bool((np.bincount(p, minlength=B) == 1).all())):
+        raise GnmError("perm is not a permutation of 0 .. %d" % (B - 1))
+    return p
+
+
+def perm_to_device(perm, B, dev, out=None):
+    """perm -> int32 device tensor (or into the static buffer `out`).  Host permutations are validated and go through
+    pinned memory (a pageable copy would stall the host behind everything queued); a CUDA tensor is taken as it is --
+    it can only come from a buffer that was filled through this function."""
+    if torch.is_tensor(perm) and perm.is_cuda:
+        t = perm.to(torch.int32)
+        if out is not None and out.data_ptr() != t.data_ptr():
+            out.copy_(t, non_blocking=True)
+        return t if out is None else out
+    host = torch.as_tensor(check_permutation(perm.cpu().numpy() if torch.is_tensor(perm) else perm, B).astype(np.int32))
+    if dev.type == "cuda":
+        host = host.pin_memory()
+    if out is not None:
+        out.copy_(host, non_blocking=True)
+        return out
+    return host.to(dev, non_blocking=True)
+
+
 def eval_forward_fused(spec, batch, perm, P, X, want_disc, mode=True):
     """GIN_InfoMaxReg.forward in eval() mode (graphcnn.py:194-251 with BatchNorm on its running statistics and dropout
     off) as ONE encoder launch (gnm_eval_encoder: layers + readout + classifier, a workgroup per graph) plus, for the
@@ -615,10 +648,7 @@ def eval_forward_fused(spec, batch, perm, P, X, want_disc, mode=True):
             U = torch.empty((B, Wd.shape[0]), **f32)
             if not _small_gemm(c, 0, Wd, 0, U, B, Wd.shape[0], Wd.shape[1]):
                 U = c @ Wd.t()                                                # U[g] = W c_g
-            if torch.is_tensor(perm) and perm.is_cuda:
-                perm_rows = perm.to(torch.int32)
-            else:
-                perm_rows = torch.as_tensor(perm, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+            perm_rows = perm_to_device(perm, B, dev)
             d_logit = torch.empty((2 * N, 1), **f32)
             hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
             check(lib.gnm_disc_score_fwd(hp_, sp_, tp_, ldh_, L, H, U.data_ptr(), U.stride(0), perm_rows.data_ptr(),
@@ -694,13 +724,9 @@ class GinInfoMaxFn(torch.autograd.Function):
             U = torch.empty((B, Wd.shape[0]), dtype=torch.float32, device=X.device)
             if not _small_gemm(c, 0, Wd, 0, U, B, Wd.shape[0], LH):
                 U = c @ Wd.t()                                                # U[g] = W c_g
-            if torch.is_tensor(perm) and perm.is_cuda:      # graph-capture safe: already on the device
-                perm_rows = perm.to(torch.int32)
-            else:
-                # row index = perm[g] (:198-201,242).  Pinned staging + async copy: a pageable H2D copy would make
-                # the host wait until the stream has drained everything launched so far, and the GPU then
-                # idles while the host catches up
-                perm_rows = torch.as_tensor(perm, dtype=torch.int32).pin_memory().to(X.device, non_blocking=True)
+            # row index = perm[g] (:198-201,242): validated on the host, pinned staging + async copy (a device tensor --
+            # a captured step's static buffer -- passes as it is: graph-capture safe)
+            perm_rows = perm_to_device(perm, B, X.device)
             d_logit = torch.empty((2 * N, 1), dtype=torch.float32, device=X.device)
             hp_, sp_, tp_, ldh_ = _hidden_ptr_arrays(hidden)
             rc = -2
@@ -777,7 +803,8 @@ class GinInfoMaxFn(torch.autograd.Function):
             s2sum = torch.empty(B, **f32)
             dsum = torch.empty(B, **f32)
             hold = ctx.disc_unit
-            if hold is not None and hold.k is not None and hold.dD_ptr == dD.data_ptr():
+            if (hold is not None and hold.k is not None and hold.dD_ptr == dD.data_ptr()
+                    and hold.dD_version == dD._version):      # (same tensor AND untouched since the loss wrote it)
                 # dD = k (sigmoid(d_logit) - target) came straight from the loss that recorded k: the reductions are k
                 # times what the forward left (DiscUnit) -- no second pass over the hidden layers
                 inv_perm = hold.inv_perm
@@ -794,7 +821,7 @@ class GinInfoMaxFn(torch.autograd.Function):
                                                  dU.data_ptr(), dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(),
                                                  inv_perm.data_ptr(), st), "gnm_disc_score_bwd")
             if hold is not None:
-                hold.k = hold.dD_ptr = None
+                hold.k = hold.dD_ptr = hold.dD_version = None
             Wd = P["disc.f_k.weight"][0]
             # (the three [B, L*H]-sized products of the tail: csrc/sgemm.hip -- one workgroup per 32 x 32 output tile, the
             #  contraction split over its four waves, split-precision bf16 products.  A first hand-written version on the

@@ -16,7 +16,8 @@ import gc
 
 import torch
 
-from .arena import PackedStaticBatch, StaticBatch
+from .arena import BatchClassMismatch, PackedStaticBatch, StaticBatch
+from .core import perm_to_device
 
 
 
@@ -50,6 +51,7 @@ class CapturedTrainStep:
         are real steps on the template batch: parameters, BatchNorm buffers and every tensor in
         `preserve` (optimizer state) are put back afterwards, so construction has no side effect."""
         self.model = model
+        self.eager_fallbacks = 0           # replays that ran eagerly instead (a batch of another class: run())
         self._post = post_backward
         self._agg0_cache = agg0_cache      # False: aggregate the input features inside the step (bench.py)
         keep = [t for t in model.state_dict().values()] + list(preserve)
@@ -115,11 +117,18 @@ class CapturedTrainStep:
                                "add every graph before building CapturedTrainStep / FusedTrainStep, or build a new one")
         try:
             self.static.load(batch, extra=labels.to(torch.int64))
-        except ValueError:
+        except BatchClassMismatch:
             # a batch of another class than the captured one (a pool that straddles the density threshold of the
-            # matrix-core aggregation, a graph with an isolated node, another size): the same step, launched eagerly
+            # matrix-core aggregation, a graph with an isolated node, another size): the same step, launched eagerly.
+            # Counted (bench.py prints it) and announced once: a caller whose every batch lands here is not replaying.
+            # Any other ValueError of load() is API misuse and propagates.
+            self.eager_fallbacks += 1
+            if self.eager_fallbacks == 1:
+                import warnings
+                warnings.warn("CapturedTrainStep: a batch of another class than the captured one runs eagerly "
+                              "(counted in .eager_fallbacks)", RuntimeWarning, stacklevel=2)
             return self._eager(batch, labels, perm)
-        self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
+        perm_to_device(perm, self.perm.shape[0], self.perm.device, out=self.perm)
         self.graph.replay()
         return self.loss
 
@@ -160,7 +169,7 @@ class CapturedEval:
         self.static.load_gids(gh)
         dev = arena.device
         B = gh.shape[0]
-        self.perm = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.perm = torch.arange(B, dtype=torch.int32, device=dev)      # (a valid permutation from the start)
         self._params = [p for p in model.parameters()] + [b for b in model.buffers()]
         self._param_ptrs = tuple(t.data_ptr() for t in self._params)
         s = torch.cuda.Stream(device=dev)
@@ -206,7 +215,7 @@ class CapturedEval:
         self.static.load_gids(gh)
         if self.static.B > 1:      # (B = 1: the permutation of one graph is [0], as captured)
             # a fresh pinned tensor per call: torch's pinned-memory allocator keeps it alive until the copy has run
-            self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
+            perm_to_device(perm, self.perm.shape[0], self.perm.device, out=self.perm)
         self.graph.replay()
         return self.c_logit, self.d_logit, self.g_f
 
@@ -252,7 +261,8 @@ class CapturedTrain:
         self._tracked = self._params + [b for b in model.buffers()]
         self._ptrs = tuple(t.data_ptr() for t in self._tracked)
         self._req_mask = tuple(p.requires_grad for p in self._params)
-        self.outstanding = None        # weak reference to the outputs of a replayed forward that has not been backpropagated
+        self.outstanding = None        # weak reference to the hold of a replayed forward that has not been backpropagated
+        self.gen = 0                   # number of forward replays so far (claim() / _TrainReplayFn.backward)
         keep = [b for b in model.buffers()]                # BatchNorm statistics: the warm-up passes must not count
         snapshot = [t.clone() for t in keep]
         # The gradients land in ONE persistent buffer of this object (ordinary allocation, outside the graphs' memory
@@ -327,8 +337,21 @@ class CapturedTrain:
                 and tuple(p.requires_grad for p in self._params) == self._req_mask
                 and m._spec.grad_sink is None and m._spec.sync_bn is None)
 
+    class _Hold:
+        """lives on the autograd node of one replayed forward (weakly referenced from here)"""
+        __slots__ = ("__weakref__",)
+
+    def claim(self):
+        """called by the autograd Function right after forward(): (generation of that replay, an object whose lifetime
+        is the autograd node's -- while it is alive and backward has not run, the activations are taken: busy())"""
+        import weakref
+        h = CapturedTrain._Hold()
+        self.outstanding = weakref.ref(h)
+        return self.gen, h
+
     def busy(self):
-        """a replayed forward whose outputs are still alive and not yet backpropagated owns the captured activations"""
+        """a replayed forward whose autograd node is still alive (either output, or anything computed from them) and
+        not yet backpropagated owns the captured activations"""
         o = self.outstanding
         return o is not None and o() is not None
 
@@ -344,9 +367,10 @@ class CapturedTrain:
                 p.grad = g.clone()
 
     def forward(self, gh, perm):
+        self.gen += 1
         self.static.load_gids(gh)
         if self.static.B > 1:
-            self.perm.copy_(torch.as_tensor(np.asarray(perm), dtype=torch.int32).pin_memory(), non_blocking=True)
+            perm_to_device(perm, self.perm.shape[0], self.perm.device, out=self.perm)
         self.fwd_graph.replay()
         return self.c_logit, self.d_logit
 

@@ -135,9 +135,16 @@ class DataParallelGIN:
         once, and remembers.  Nothing here synchronises the host, so the call is hipGraph-capturable on "nccl"
         (bench.py captures it inside the step's graph when the capture succeeds)."""
         self.fp.attach_grads()      # callers that only ran optimizer.zero_grad(): see zero_grad()
+        self.last_needs_scale = False
         if self.world == 1 and not self.force_collective:
             return None
         g = self.fp.flat_grad
+        if async_op and not (g.is_cuda and dist.get_backend(self.group) == "gloo"):
+            # ONE contract for the asynchronous form (ADVICE r3: AVG on one path and un-scaled sums on the other left
+            # the caller guessing): always the SUM; the caller scales by 1 / world after work.wait()
+            # (FusedAdam.set_grad_scale).  `last_needs_scale` says so.
+            self.last_needs_scale = True
+            return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if g.is_cuda and dist.get_backend(self.group) == "gloo":
             # gloo has no device path worth the name: handing it a CUDA tensor makes it stage through pageable
             # memory on internal streams (measured 8 ms for 569 KB, and 300 ms when a hipGraph replay was still in
@@ -153,37 +160,54 @@ class DataParallelGIN:
             return None
         if self._avg_ok is not False and dist.get_backend(self.group) == "nccl":
             try:
-                work = dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
                 self._avg_ok = True
-                return work if async_op else None
+                return None
             except (RuntimeError, ValueError) as e:
                 if self._avg_ok:            # it worked before: this is a real failure, not a missing feature
                     raise
                 self._avg_ok = False
                 self.avg_fallback_reason = "%s: %s" % (type(e).__name__, e)
-        work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
-        if async_op:
-            return work             # caller scales (FusedAdam.set_grad_scale) after work.wait()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
         g.div_(self.world)
         return None
 
 
-def choose_launch_mode(candidates, measure):
+def choose_launch_mode(candidates, measure, agree=None, errors=None):
     """Pick how a multi-rank step is launched.  candidates: mode names in order of preference (bench.py: "graph+cc" =
     hipGraph replay with the all-reduce captured inside, "graph" = replay + collective behind it, "eager");
     measure(name) -> seconds per step with that mode, already MAX-reduced over the ranks so that every rank takes
     the same decision.  A candidate whose measurement raises is dropped (e.g. a captured collective that fails at
-    replay); ties go to the earlier candidate.  Returns (mode, {name: seconds})."""
+    replay); ties go to the earlier candidate.  Returns (mode, {name: seconds}).
+
+    measure() contains collectives, so a failure on ONE rank must take the candidate out on ALL of them, or the others
+    sit in its all-reduce while this one has moved on: agree(ok) -> bool is the MIN over the ranks of a success flag
+    (bench.py: a one-int all-reduce), called once per candidate after its measurement.  The exception text of a dropped
+    candidate is kept in `errors` (a dict, name -> text).  A failure that is a GPU fault rather than a declined
+    capture is not survivable: it is re-raised so that the process exits non-zero."""
     times = {}
     for name in candidates:
+        ok, t = True, float("nan")
         try:
             t = float(measure(name))
-        except Exception:
-            continue
-        if t == t and t > 0.0:              # not NaN, a real duration
+        except Exception as e:
+            text = "%s: %s" % (type(e).__name__, e)
+            if errors is not None:
+                errors[name] = text
+            low = text.lower()
+            if any(k in low for k in ("memory access fault", "hiperrorillegaladdress", "illegal memory access",
+                                      "hiperrorlaunchfailure", "device-side assert")):
+                raise
+            ok = False
+        if not (t == t and t > 0.0):        # NaN or not a duration
+            ok = False
+        if agree is not None:
+            ok = bool(agree(ok))
+        if ok:
             times[name] = t
     if not times:
-        raise RuntimeError("no launch mode could be measured (candidates: %s)" % ", ".join(candidates))
+        raise RuntimeError("no launch mode could be measured (candidates: %s)%s" % (
+            ", ".join(candidates), "; " + "; ".join("%s -> %s" % kv for kv in (errors or {}).items()) if errors else ""))
     best = min(times, key=lambda k: (times[k], list(candidates).index(k)))
     return best, times
 

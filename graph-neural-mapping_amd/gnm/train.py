@@ -74,6 +74,7 @@ class _InfomaxLossFn(torch.autograd.Function):
             ctx.hold.k = g.reshape(1)
             ctx.hold.kscale = float(np.float32(beta) / np.float32(M))
             ctx.hold.dD_ptr = dD.data_ptr()
+            ctx.hold.dD_version = dD._version      # an in-place gradient hook (g.clamp_(), g.mul_()) keeps the pointer
         return dC, dD, None, None, None, None, None
 
 

@@ -110,11 +110,20 @@ class _TrainReplayFn(torch.autograd.Function):
     def forward(ctx, cap, gh, perm, *params):
         c_logit, d_logit = cap.forward(gh, perm)
         ctx.cap = cap
+        # The capture's activations belong to THIS forward until its backward has run.  `hold` lives exactly as long as
+        # this autograd node -- i.e. while either output or anything computed from them is alive (a weak reference to
+        # c_logit alone, as in round 3, let `_, d = model(b)` look finished) -- and the generation number lets backward
+        # prove that no later replay has overwritten them.
+        ctx.gen, ctx.hold = cap.claim()
         ctx.set_materialize_grads(False)
         return c_logit.clone(), d_logit.clone()
 
     @staticmethod
     def backward(ctx, dC, dD):
+        if ctx.gen != ctx.cap.gen:
+            raise RuntimeError("train replay: the captured activations of this forward were overwritten by a later "
+                               "forward before its backward ran (generation %d, now %d); set model.train_replay = False "
+                               "for this pattern" % (ctx.gen, ctx.cap.gen))
         return (None, None, None) + tuple(ctx.cap.backward(dC, dD))
 
 
@@ -359,8 +368,6 @@ class GIN_InfoMaxReg(nn.Module):
         perm = np.random.permutation(B)                                       # graphcnn.py:199, consumed as always
         names, tensors, _ = self._param_lists()
         c_logit, d_logit = _TrainReplayFn.apply(ct, gh, perm, *tensors)
-        import weakref
-        ct.outstanding = weakref.ref(c_logit)
         return c_logit, d_logit
 
     # ------------------------------------------------------------------ reference API

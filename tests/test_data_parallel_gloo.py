@@ -74,7 +74,17 @@ def _worker(rank, world, port, case, learn_eps, out_dir):
                 p.grad.add_(torch.from_numpy(np.asarray(local[name], dtype=np.float32).reshape(p.shape)))
         for name, p in model.named_parameters():             # grads are views of the flat buffer
             assert p.grad.data_ptr() >= dp.fp.flat_grad.data_ptr()
+        before = dp.fp.flat_grad.clone()
         dp.allreduce_gradients()
+        assert dp.last_needs_scale is False                  # the synchronous form returns the mean
+        # the asynchronous form has ONE contract: un-scaled sums + last_needs_scale, on every backend
+        mean_sync = dp.fp.flat_grad.clone()
+        dp.fp.flat_grad.copy_(before)
+        work = dp.allreduce_gradients(async_op=True)
+        assert work is not None and dp.last_needs_scale is True
+        work.wait()
+        assert torch.allclose(dp.fp.flat_grad / world, mean_sync, rtol=1e-6, atol=0)
+        dp.fp.flat_grad.copy_(mean_sync)
         np.save(os.path.join(out_dir, f"flat_{rank}.npy"), dp.fp.flat_grad.numpy())
         np.save(os.path.join(out_dir, f"local_{rank}.npy"),
                 np.concatenate([np.asarray(local.get(n, np.zeros(p.shape)), dtype=np.float64).reshape(-1)

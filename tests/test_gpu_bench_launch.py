@@ -25,6 +25,16 @@ def test_bench_two_ranks_without_a_launcher():
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert out["config"]["global_batch"] == 64 and out["config"]["graphs_per_gpu"] == 32
     assert out["value"] > 0 and out["ms_per_step"] < 200, out["ms_per_step"]     # round 1: 279-404 ms through gloo
+    # the object the first real `bench.py --gpus 8` line will carry: who took part, what the
+    # collective was, how the launch mode was chosen, and that the ranks agree where they must
+    cc = out["collective"]
+    assert cc["world"] == 2 and cc["backend"] == "gloo" and cc["forced_single_rank_test_hook"] is False
+    assert cc["op"].startswith("gloo staging"), cc
+    assert set(cc["launch_mode_trial_ms"]) >= {"graph", "eager"} and cc["launch_mode"] in cc["launch_mode_trial_ms"], cc
+    rc = cc["rank_check"]
+    assert rc["params_agree_after_broadcast"] is True and rc["grads_agree_after_allreduce"] is True, rc
+    assert rc["grad_abs_sum"] > 0 and len(rc["final_loss_per_rank"]) == 2
+    assert all(v == v and abs(v) < 1e6 for v in rc["final_loss_per_rank"])
 
 
 @pytest.mark.gpu

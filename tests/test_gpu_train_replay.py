@@ -92,6 +92,51 @@ def test_second_forward_before_backward_takes_the_eager_path():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("pattern", ["keep_d_only", "temporaries"])
+def test_a_forward_whose_graph_is_alive_is_never_replayed_over(pattern):
+    """the capture's activations are owned by a forward until its backward ran.  Round 3 tracked that through
+    a weak reference to c_logit alone, so (a) `_, d = model(b1)` and (b) losses computed from temporaries looked
+    finished, the second forward replayed over the first one's activations and the first backward produced the SECOND
+    batch's gradients.  Both patterns must equal the eager model bitwise."""
+    graphs = make_task(16)
+
+    def run(model):
+        np.random.seed(3)
+        if pattern == "keep_d_only":
+            _, d1 = model(graphs[:8])
+            _, d2 = model(graphs[8:16])
+            (d1.square().mean() + 2.0 * d2.square().mean()).backward()
+        else:
+            f = lambda out: out[0].sum() + out[1].square().mean()
+            l1 = f(model(graphs[:8]))
+            l2 = f(model(graphs[8:16]))
+            (l1 + 3.0 * l2).backward()
+        return [p.grad.clone() for p in model.parameters() if p.grad is not None]
+
+    got = run(build(replay=True))
+    want = run(build(replay=False))
+    assert len(got) == len(want)
+    for x, y in zip(got, want):
+        assert torch.equal(x, y)
+
+
+def test_backward_of_an_overwritten_replay_raises():
+    """the generation check behind the liveness tracking: a backward whose activations were replayed over must not
+    produce numbers"""
+    from models.graphcnn import _TrainReplayFn
+    graphs = make_task(8)
+    model = build(replay=True)
+    np.random.seed(1)
+    c, d = model(graphs)
+    ct = next(iter(model._train_cache.values()))
+    ct.outstanding = None                  # pretend the tracking lost it
+    c2, d2 = model(graphs)                 # replays over the first forward's activations
+    assert ct.gen == 2
+    with pytest.raises(RuntimeError, match="overwritten"):
+        (c.sum() + d.mean()).backward()
+    (c2.sum() + d2.mean()).backward()      # the live one is fine
+
+
 def test_replay_with_dropout_runs_and_draws_fresh_masks():
     graphs = make_task(8)
     model = build(dropout=0.5, replay=True)

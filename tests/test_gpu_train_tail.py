@@ -324,3 +324,28 @@ def test_discriminator_hand_over_is_not_used_when_the_gradient_was_summed():
         res.append({k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()})
     for k in res[0]:
         assert np.array_equal(res[0][k], res[1][k]), k          # the same kernels ran: bitwise
+
+
+def test_discriminator_hand_over_is_not_used_when_a_hook_edits_the_gradient_in_place():
+    """an in-place tensor hook on d_logit (g.mul_(0.5)) keeps the gradient's address, so the pointer check
+    alone took the k x unit shortcut and ignored the edit for dU / dWd / the readout path.  The gradient's version
+    counter is part of the hand-over now: same bits as the run without any hand-over."""
+    from gnm.train import infomax_loss
+    from helpers import load_case
+    from test_gpu_model_parity import make_graphs, make_model
+    cfg, state, d = load_case("tiny_s1_eps1_gsum_nsum")
+    graphs = make_graphs(cfg, d)
+    labels = torch.tensor([g.label for g in graphs], device=DEV)
+    res = []
+    for hand_over in (True, False):
+        model = make_model(cfg, state).train()
+        model.train_replay = False
+        np.random.seed(3)
+        c_logit, d_logit = model(graphs)
+        if not hand_over:
+            del d_logit._gnm_disc_unit
+        d_logit.register_hook(lambda g: g.mul_(0.5))
+        infomax_loss(c_logit, d_logit, labels, 0.05)[0].backward()
+        res.append({k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()})
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k

@@ -242,6 +242,16 @@ def test_choose_launch_mode_trial_logic():
     assert mode == "eager" and list(times) == ["eager"]
     with pytest.raises(RuntimeError):
         choose_launch_mode(["graph"], lambda n: (_ for _ in ()).throw(ValueError("x")))
+    # a candidate that failed on ANOTHER rank is dropped here as well (agree = MIN over the ranks of the success flag),
+    # the exception text is kept, and a GPU fault is not swallowed
+    errs = {}
+    mode, times = choose_launch_mode(["graph+cc", "graph", "eager"], flaky, agree=lambda ok: ok, errors=errs)
+    assert mode == "eager" and "captured collective failed" in errs["graph+cc"]
+    veto = iter([False, True, True])
+    mode, times = choose_launch_mode(["graph+cc", "graph", "eager"], lambda n: 1e-3, agree=lambda ok: ok and next(veto))
+    assert mode == "graph" and "graph+cc" not in times
+    with pytest.raises(RuntimeError, match="Memory access fault"):
+        choose_launch_mode(["graph", "eager"], lambda n: (_ for _ in ()).throw(RuntimeError("Memory access fault by GPU")))
 
 
 def test_allreduce_gradients_is_a_mean_and_a_noop_for_one_rank():
