@@ -390,6 +390,9 @@ def main():
             bt.maxnb = MaxNeighbours([pool[j] for j in sels[i]], args.no_learn_eps, dev)
             prebuilt.append((bt, lab))
     template = assemble(0)[0] if prebuilt is None else prebuilt[0][0]
+    # replayed steps take the ids, labels and permutation through ONE pinned upload (CapturedTrainStep.run_gids)
+    labels_host = np.array([g.label for g in pool], dtype=np.int64)
+    packed_gids = gids_all[sels[0]] if (prebuilt is None and template.equal_n) else None
     N = template.N
     d_labels = torch.cat([torch.ones(N, 1), torch.zeros(N, 1)], 0).to(dev)   # main.py:32, sized by node count
 
@@ -411,7 +414,7 @@ def main():
         from gnm.graphs import CapturedTrainStep
         try:
             captured = CapturedTrainStep(model, template, loss_fn, zero_grad=dp.zero_grad,
-                                         agg0_cache=args.agg0_cache)
+                                         agg0_cache=args.agg0_cache, gids_host=packed_gids)
         except Exception as e:                      # capture is an optimisation: fall back to eager launches
             print("hipGraph capture failed (%s: %s); running eagerly" % (type(e).__name__, e), file=sys.stderr)
             capture_notes["step"] = "%s: %s" % (type(e).__name__, e)
@@ -428,7 +431,8 @@ def main():
             # collective outside.  Which variant runs is decided by the timed trial below.
             try:
                 captured_cc = CapturedTrainStep(model, template, loss_fn, zero_grad=dp.zero_grad,
-                                                agg0_cache=args.agg0_cache, post_backward=dp.allreduce_gradients)
+                                                agg0_cache=args.agg0_cache, post_backward=dp.allreduce_gradients,
+                                                gids_host=packed_gids)
             except Exception as e:
                 print("capturing the all-reduce inside the step's hipGraph failed (%s: %s); it stays outside"
                       % (type(e).__name__, e), file=sys.stderr)
@@ -456,6 +460,15 @@ def main():
         return None if args.agg0_cache else arena.features(bt)
 
     def step(i, eager=False):
+        replay = (mode in ("graph", "graph+cc")) and not eager
+        if replay and packed_gids is not None:
+            # batch assembly of a replayed step: host index arithmetic + one upload, inside the timed region
+            cap = captured_cc if mode == "graph+cc" else captured
+            loss = cap.run_gids(gids_all[sels[i]], labels_host[sels[i]], perms[i])
+            if mode == "graph+cc":
+                return loss                                      # the all-reduce is part of the replayed graph
+            dp.allreduce_gradients()
+            return loss
         bt, lab = assemble(i) if prebuilt is None else prebuilt[i]
         if mode == "graph+cc" and not eager:
             return captured_cc.run(bt, lab, perms[i])           # the all-reduce is part of the replayed graph
@@ -536,19 +549,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if timer is None and not args.no_kernel_timer and rank == 0:
-        # replayed steps carry no HIP events: time the two roofline kernels on a few eager steps of the same
-        # batches, after (and outside) the timed region
-        core.TIMER = core.KernelTimer(("agg_fwd_F%d" % H, "agg_bwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
-        for i in range(min(3, nsteps)):
-            bt, lab = assemble(i) if prebuilt is None else prebuilt[i]
-            c_logit, d_logit = model.forward_batch(bt, X=feats(bt), perm=perms[i])
-            loss_fn(c_logit, d_logit, lab).backward()
-        torch.cuda.synchronize()
-        timer, core.TIMER = core.TIMER, None
     loss_val = float(loss.item())
-    if not np.isfinite(loss_val):
-        raise SystemExit("non-finite loss %r" % loss_val)
     rank_check = None
     if multi:
         # What the ranks must agree on after a step: the parameters (broadcast once, then only read here) and the
@@ -568,6 +569,18 @@ def main():
                       "grads_agree_after_allreduce": bool((allv[:, 1] == allv[0, 1]).all() and (allv[:, 2] == allv[0, 2]).all()),
                       "grad_abs_sum": float(allv[0, 2]), "final_loss_per_rank": [float(v) for v in allv[:, 3]]}
 
+    if timer is None and not args.no_kernel_timer and rank == 0:
+        # replayed steps carry no HIP events: time the two roofline kernels on a few eager steps of the same
+        # batches, after (and outside) the timed region
+        core.TIMER = core.KernelTimer(("agg_fwd_F%d" % H, "agg_bwd_F%d" % H, "lin_fwd_K%d_H%d" % (H, H)))
+        for i in range(min(3, nsteps)):
+            bt, lab = assemble(i) if prebuilt is None else prebuilt[i]
+            c_logit, d_logit = model.forward_batch(bt, X=feats(bt), perm=perms[i])
+            loss_fn(c_logit, d_logit, lab).backward()
+        torch.cuda.synchronize()
+        timer, core.TIMER = core.TIMER, None
+    if not np.isfinite(loss_val):
+        raise SystemExit("non-finite loss %r" % loss_val)
     if rank == 0:
         total_graphs = B * world * args.steps
         out = {
@@ -587,8 +600,10 @@ def main():
                        "graphs_per_gpu": B, "global_batch": B * world, "nodes_per_graph": n, "edges_per_graph": E,
                        "pool_graphs_per_gpu": pool_n, "parallelism": "dp%d" % world},
             "final_loss": loss_val, "setup_seconds": round(t_gen, 1),
-            "batch_assembly": ("inside the timed step: arena.batch_from_gids + label gather per step (graphcnn.py:84-134, "
-                               "195 in the reference's forward)" if prebuilt is None else
+            "batch_assembly": ("inside the timed step (graphcnn.py:84-134, 195 in the reference's forward): replayed steps "
+                               "-- arena ids, labels and permutation packed on the host, one pinned upload, feature "
+                               "gather on the device; eager steps -- arena.batch_from_gids + label gather"
+                               if prebuilt is None else
                                "outside the timed region (max pooling: Python neighbour lists per graph)"),
             "eager_fallbacks": int(getattr(captured, "eager_fallbacks", 0)) if captured is not None else None,
             "host_enqueue_ms_per_step": 1e3 * t_enqueued / args.steps,

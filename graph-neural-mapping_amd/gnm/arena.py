@@ -523,10 +523,13 @@ class PackedStaticBatch:
     (gnm/graphs.py CapturedEval): assembling a Batch the general way costs ~15 tiny device ops (~150 us of host
     time), which is most of a B = 1 forward."""
 
-    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False, iso=False, has_bits=False):
+    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False, iso=False, has_bits=False, extra_words=0):
+        """extra_words: int64 words appended to the buffer for the caller's own per-batch values (a training step's
+        labels and Infomax permutation: gnm/graphs.py), uploaded by the same copy: load_gids(gh, extra)."""
         dev = arena.device
         self.arena, self.B, self.n = arena, int(B), int(n)
-        words = 8 * B + (B + 2) // 2                       # 8 int64 vectors + node_off as int32 pairs
+        self._base_words = 8 * B + (B + 2) // 2           # 8 int64 vectors + node_off as int32 pairs
+        words = self._base_words + int(extra_words)
         node_off = np.arange(B + 1, dtype=np.int64) * n
         # a small ring of pinned staging buffers: the copy is asynchronous, so a buffer may only be rewritten once
         # the copy that read it has run (an event per slot; by the time a slot comes round again it has)
@@ -539,6 +542,15 @@ class PackedStaticBatch:
             self._ring.append(h)
             self._events.append(None)
         self._dev = torch.zeros(words, dtype=torch.int64, device=dev)
+        # The upload itself runs on a side stream into a per-slot device staging buffer and reaches the buffer the
+        # captured kernels read through a device-to-device copy on the caller's stream (round 4).  A host-to-device
+        # copy queued on the compute stream is a DMA-engine transfer between two replays: it starts when the previous
+        # replay has drained and the next one waits for it (~40 us per step measured); from the side stream it passes
+        # while the previous step computes.  GNM_PACKED_DIRECT=1: the direct copy (A/B).
+        self._two_stage = dev.type == "cuda" and os.environ.get("GNM_PACKED_DIRECT") is None
+        self._side = torch.cuda.Stream(device=dev) if self._two_stage else None
+        self._stage_dev = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in self._ring] if self._two_stage else None
+        self._done = [None] * len(self._ring)
         dv = self._dev
         b = Batch()
         b.arena, b.B, b.N, b.n_max, b.n_min, b.nnz_max = arena, int(B), int(B * n), int(n), int(n), int(nnz_max)
@@ -552,9 +564,10 @@ class PackedStaticBatch:
         b.t_rp_off, b.t_col_off = (b.rp_off, b.col_off) if symmetric else (dv[2 * B:3 * B], dv[3 * B:4 * B])
         b.gids = dv[4 * B:5 * B]
         b.feat_base = dv[5 * B:6 * B]
-        b.node_off = dv[8 * B:].view(torch.int32)[:B + 1]
+        b.node_off = dv[8 * B:self._base_words].view(torch.int32)[:B + 1]
         b.node_off_host = node_off
         self.batch = b
+        self.extra = dv[self._base_words:] if extra_words else None
         self._dev.copy_(self._ring[0])
 
     def fits(self, gh):
@@ -567,7 +580,8 @@ class PackedStaticBatch:
                 and self.arena.dense_ok(gh) == b.dense and bool(tb["iso_host"][gh].any()) == b.iso
                 and bool(tb["bits_ok_host"][gh].all()) == b.has_bits)
 
-    def load_gids(self, gh):
+    def load_gids(self, gh, extra=None):
+        """extra: host int64 array filling the extra words (all of them), or None"""
         tb = self.arena._tables()
         i = self._next
         self._next = (i + 1) % len(self._ring)
@@ -583,6 +597,23 @@ class PackedStaticBatch:
         np.take(tb["feat_host"], gh, out=hv[5 * B:6 * B])
         np.take(tb["bits_host"], gh, out=hv[6 * B:7 * B])
         np.take(tb["tbits_host"], gh, out=hv[7 * B:8 * B])
+        if extra is not None:
+            hv[self._base_words:] = extra
+        if self._two_stage:
+            main = torch.cuda.current_stream(self._dev.device)
+            if self._events[i] is None:
+                self._events[i] = torch.cuda.Event()
+            if self._done[i] is not None:
+                self._side.wait_event(self._done[i])       # slot i's staging buffer: its last reader (on `main`) is through
+            with torch.cuda.stream(self._side):
+                self._stage_dev[i].copy_(self._ring[i], non_blocking=True)
+                self._events[i].record(self._side)
+            main.wait_event(self._events[i])
+            self._dev.copy_(self._stage_dev[i], non_blocking=True)
+            if self._done[i] is None:
+                self._done[i] = torch.cuda.Event()
+            self._done[i].record(main)
+            return
         self._dev.copy_(self._ring[i], non_blocking=True)
         if self._dev.is_cuda:
             if self._events[i] is None:

@@ -44,12 +44,17 @@ def _capture(graph, pool=None):
 
 class CapturedTrainStep:
     def __init__(self, model, template_batch, loss_fn, zero_grad=None, warmup=3, post_backward=None, preserve=(),
-                 agg0_cache=True):
+                 agg0_cache=True, gids_host=None):
         """loss_fn(c_logit, d_logit, labels) -> scalar loss.  zero_grad(): clears the
         gradient buffers (default: model.zero_grad(set_to_none=False)).  post_backward(): extra
         capturable work recorded after backward (e.g. a fused optimizer step).  The warm-up passes
         are real steps on the template batch: parameters, BatchNorm buffers and every tensor in
-        `preserve` (optimizer state) are put back afterwards, so construction has no side effect."""
+        `preserve` (optimizer state) are put back afterwards, so construction has no side effect.
+
+        gids_host (round 4): the template batch's arena ids on the host, for equal-size graphs.  The step is then
+        captured on a PackedStaticBatch whose ONE buffer also carries the labels and the Infomax permutation, and
+        run_gids(ids, labels, perm) feeds a replay with O(B) host index arithmetic and ONE pinned upload -- instead of
+        a Batch assembled by six device gathers, two uploads and a concatenation (~75 us of launches per step)."""
         self.model = model
         self.eager_fallbacks = 0           # replays that ran eagerly instead (a batch of another class: run())
         self._post = post_backward
@@ -58,9 +63,25 @@ class CapturedTrainStep:
         snapshot = [t.clone() for t in keep]
         dev = template_batch.node_off.device
         B = template_batch.B
-        self.static = StaticBatch(template_batch, extra_int64=B)      # the labels ride in the same buffer
-        self.labels = self.static.extra
-        self.perm = torch.arange(B, dtype=torch.int32, device=dev)
+        self.packed = None
+        if gids_host is not None and template_batch.equal_n and B > 0:
+            gh = np.asarray(gids_host, dtype=np.int64)
+            arena = template_batch.arena
+            tb = arena._tables()
+            nnz = int(tb["nnz_host"][gh].max())
+            nnz_cap = max(4096, 1 << (nnz - 1).bit_length()) if nnz > 0 else 4096
+            self._perm_words = (B + 1) // 2
+            self.packed = PackedStaticBatch(arena, B, template_batch.n_max, template_batch.symmetric, nnz_cap,
+                                            dense=template_batch.dense, iso=template_batch.iso,
+                                            has_bits=template_batch.has_bits, extra_words=B + self._perm_words)
+            self.packed.load_gids(gh, self._pack_extra(np.zeros(B, dtype=np.int64), np.arange(B)))
+            self.static = self.packed
+            self.labels = self.packed.extra[:B]
+            self.perm = self.packed.extra[B:].view(torch.int32)[:B]
+        else:
+            self.static = StaticBatch(template_batch, extra_int64=B)      # the labels ride in the same buffer
+            self.labels = self.static.extra
+            self.perm = torch.arange(B, dtype=torch.int32, device=dev)
         self.loss = None
         self._zero = zero_grad or (lambda: model.zero_grad(set_to_none=False))
         self._loss_fn = loss_fn
@@ -104,11 +125,62 @@ class CapturedTrainStep:
             self._post()
         return loss
 
+    def _pack_extra(self, labels_host, perm_host):
+        B = labels_host.shape[0]
+        ex = np.zeros(B + self._perm_words, dtype=np.int64)
+        ex[:B] = labels_host
+        ex[B:].view(np.int32)[:B] = perm_host
+        return ex
+
+    def _check_arena(self):
+        if self._agg0_cache:        # graphs added since the capture: their layer-0 aggregate must exist before a replay
+            sp = self.model._spec
+            self.static.batch.arena.refresh_agg0(sp.n_avg, not sp.learn_eps)
+        if self._arena_buffers() != self._arena_ptrs:
+            raise RuntimeError("the graph arena was re-allocated after this step was captured (graphs were added): "
+                               "add every graph before building CapturedTrainStep / FusedTrainStep, or build a new one")
+
+    def run_gids(self, gids_host, labels_host, perm=None):
+        """Replay the step on the graphs with arena ids `gids_host` (host int64), labels `labels_host` (host ints):
+        what a data loader hands over.  Needs the packed form (gids_host given at construction).  A selection of
+        another class than the captured one runs the same step eagerly, like run()."""
+        if self.packed is None:
+            raise RuntimeError("run_gids needs a step captured with gids_host=...")
+        from .core import check_permutation
+        gh = np.asarray(gids_host, dtype=np.int64)
+        B = self.packed.B
+        perm = check_permutation(np.random.permutation(B) if perm is None else perm, B)
+        self._check_arena()
+        if not self.packed.fits(gh):
+            self.eager_fallbacks += 1
+            arena = self.packed.arena
+            bt = arena.batch_from_gids(gh)
+            lab = torch.as_tensor(np.asarray(labels_host, dtype=np.int64)).to(arena.device)
+            return self._eager(bt, lab, perm)
+        self.packed.load_gids(gh, self._pack_extra(np.asarray(labels_host, dtype=np.int64), perm))
+        self.graph.replay()
+        return self.loss
+
     def run(self, batch, labels, perm=None):
         """Replay the step on `batch` (same shape as the template).  perm: the
         np.random.permutation(B) of graphcnn.py:199 (drawn here if None)."""
         if perm is None:
             perm = np.random.permutation(batch.B)
+        if self.packed is not None:
+            # (captured on the packed buffer: a ready-made Batch is copied in vector by vector -- the general route)
+            self._check_arena()
+            b = self.packed.batch
+            if (batch.B, batch.N, batch.n_max, batch.n_min, batch.symmetric, batch.dense, batch.iso) != \
+                    (b.B, b.N, b.n_max, b.n_min, b.symmetric, b.dense, b.iso) or batch.nnz_max > b.nnz_max:
+                self.eager_fallbacks += 1
+                return self._eager(batch, labels, perm)
+            for name in ("rp_off", "col_off", "gids", "feat_base", "bits_off") + \
+                    (() if b.symmetric else ("t_rp_off", "t_col_off", "t_bits_off")):
+                getattr(b, name).copy_(getattr(batch, name), non_blocking=True)
+            self.labels.copy_(labels.to(torch.int64), non_blocking=True)
+            perm_to_device(perm, self.perm.shape[0], self.perm.device, out=self.perm)
+            self.graph.replay()
+            return self.loss
         if self._agg0_cache:        # graphs added since the capture: their layer-0 aggregate must exist before a replay
             sp = self.model._spec
             batch.arena.refresh_agg0(sp.n_avg, not sp.learn_eps)

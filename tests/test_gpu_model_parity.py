@@ -450,6 +450,27 @@ def test_hipgraph_replay_matches_eager_bitwise():
         got = [loss.detach().clone()] + [p.grad.clone() for p in m2.parameters()]
         for a, b in zip(got, ref):
             assert torch.equal(a, b)
+    # round 4: the packed form -- arena ids, labels and permutation through ONE pinned upload (run_gids), and a ready
+    # Batch through the same capture (run); a permutation that is not one is refused on the host
+    from gnm._cabi import GnmError
+    m3, ar3, gids3 = fresh()
+    for p in m3.parameters():
+        p.grad = torch.zeros_like(p)
+    labels_host = np.array([g.label for g in pool], dtype=np.int64)
+    cap3 = CapturedTrainStep(m3, ar3.batch_from_gids(gids3[sels[0]]), loss_fn, gids_host=gids3[sels[0]])
+    assert cap3.packed is not None
+    for k, (sel, perm, ref) in enumerate(zip(sels, perms, eager)):
+        if k == 1:
+            loss = cap3.run(ar3.batch_from_gids(gids3[sel]), labels_all[torch.as_tensor(sel, device=dev)], perm)
+        else:
+            loss = cap3.run_gids(gids3[sel], labels_host[sel], perm)
+        torch.cuda.synchronize()
+        got = [loss.detach().clone()] + [p.grad.clone() for p in m3.parameters()]
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    assert cap3.eager_fallbacks == 0
+    with pytest.raises(GnmError, match="permutation"):
+        cap3.run_gids(gids3[sels[0]], labels_host[sels[0]], np.array([0, 0, 1, 2]))
 
 
 @pytest.mark.parametrize("case", ["tiny_s0_eps1_gsum_nsum", "tiny_s1_eps0_gaverage_nsum", "tiny_s2_mlp1",
