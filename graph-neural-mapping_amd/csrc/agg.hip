@@ -206,12 +206,14 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
         }
         tile[i] = v;
     }
-    if (tid < LPR) tile[n * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // row n = zeros (padding slots)
+    constexpr int ZR = LPR == 8 ? 2 : 1;       // zero rows behind the tile (LPR == 8: one of each parity, see phase B)
+    if (tid < ZR * LPR) tile[n * LPR + tid] = make_float4(0.f, 0.f, 0.f, 0.f);  // row n (, n + 1) = zeros (padding slots)
     // row offsets staged behind the tile (wave-cooperative path only: the narrow path keeps its id block there)
-    int* rp_s = reinterpret_cast<int*>(smem + (size_t)(n + 1) * (FS * 4));
+    int* rp_s = reinterpret_cast<int*>(smem + (size_t)(n + ZR) * (FS * 4));
     const bool stage_rp = !(LPR <= 4 && p.ids_in_lds);
     if (stage_rp)
         for (int i = tid; i <= n; i += nthreads) rp_s[i] = rp[i];
+    if (LPR == 8 && tid == 0) rp_s[n + 1] = nthreads >> 6;      // the group ticket (phase B): every wave's first group is its own number
     GNM_GSTAMP(1)
     GNM_GSTAMP(2)
     __syncthreads();
@@ -323,31 +325,54 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     // per-row global round trip: the 9 row offsets come from LDS as a lane vector fetched one group ahead, the 8 id
     // chunks of a group are requested together.
     if constexpr (LPR == 8) {
+        // Bank conflicts (round 4).  A 128-byte row lies on banks 0-31 or 32-63 by the parity of its index, and the
+        // hardware serves a ds_read_b128 in 16-lane groups that put the neighbours of slots (0, 3), (1, 2), (4, 7),
+        // (5, 6) on the same cycle: equal parity there = a 2-way conflict (a third of this kernel's LDS cycles in
+        // round 3's PMC).  The arena orders every CSR row so that slots 0, 1, 4, 5 get even ids and slots 2, 3, 6, 7
+        // odd ones while the row has both (host.cpp gnm_csr_parity_order); padding slots read the zero row of the
+        // parity their slot wants (rows n and n + 1 are both zero).
+        const unsigned zero_row_pad = (unsigned)(n + ((n ^ (slot >> 1)) & 1)) * (FS * 4);
         const int ngroups = p.y ? (n + 7) >> 3 : 0;
         const unsigned jl2 = 2u * (unsigned)jlane;
         const bool hi8 = (lane & 8) != 0;
+        // Round 4: groups are handed out by an LDS ticket (a wave's first group is its own number, the counter starts
+        // at nwaves) -- the static deal left the median wave idle for 17 % of the workgroup's life behind the waves
+        // whose rows happened to have more than 32 neighbours (in-kernel timeline, profiles/r04_c4_timeline.md) -- and
+        // the NEXT group's row bounds and first id chunks are requested in the middle of the current one (one exposed
+        // L2 round trip per group before).  A row's own sum does not depend on which wave takes it.
+        int* const ticket = rp_s + n + 1;
         int g = wave;
-        int rpv = 0, nrpv = 0;
-        if (g < ngroups) rpv = rp_s[min(8 * g + (lane & 15), n)];
-        for (; g < ngroups; g += nwaves) {
-            if (g + nwaves < ngroups) nrpv = rp_s[min(8 * (g + nwaves) + (lane & 15), n)];
+        int rpv = 0;
+        unsigned raw[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) raw[r] = 0u;
+        if (g < ngroups) {
+            rpv = rp_s[min(8 * g + (lane & 15), n)];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) raw[r] = load_id(cl, 2u * (unsigned)__builtin_amdgcn_readlane(rpv, r) + jl2);
+        }
+        while (g < ngroups) {                                       // wave-uniform
+            int gn = 0;
+            if (lane == 0) gn = atomicAdd(ticket, 1);                // (read after the first four rows)
             int bnd[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) bnd[i] = __builtin_amdgcn_readlane(rpv, i);
-            unsigned raw[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) raw[r] = load_id(cl, 2u * (unsigned)bnd[r] + jl2);   // unconditional (arena slack)
             const int v = 8 * g + slot;
             const float4 self = tile[min(v, n) * LPR + sub];       // ahead of the gather (row n = zeros)
             float4 acc[8];
+            int nrpv = 0;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
+                if (r == 4) {                                       // the next group's bounds: an LDS read under rows 4-7
+                    gn = __builtin_amdgcn_readfirstlane(gn);
+                    nrpv = rp_s[min(8 * gn + (lane & 15), n)];      // (exhausted ticket: every bound = rp[n], reads the slack)
+                }
                 const int beg = bnd[r], end = bnd[r + 1];
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
                 for (int e0 = beg; e0 < end; e0 += 64) {
                     const int cnt = min(64, end - e0);
                     const unsigned rw = (e0 == beg) ? raw[r] : load_id(cl, 2u * (unsigned)e0 + jl2);
-                    const unsigned valb = (jlane < cnt) ? rw * (FS * 4) : zero_row_b;
+                    const unsigned valb = (jlane < cnt) ? rw * (FS * 4) : zero_row_pad;
                     {
                         const f32x4 t0 = lds_read16(bcast8<0>(valb) + subb), t1 = lds_read16(bcast8<1>(valb) + subb),
                                     t2 = lds_read16(bcast8<2>(valb) + subb), t3 = lds_read16(bcast8<3>(valb) + subb);
@@ -361,6 +386,9 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                 }
                 acc[r] = a;
             }
+            // the next group's first id chunks: in flight under the combine, the epilogue and the stores
+#pragma unroll
+            for (int r = 0; r < 8; ++r) raw[r] = load_id(cl, 2u * (unsigned)__builtin_amdgcn_readlane(nrpv, r) + jl2);
             // transposing combine: lane bit 5 picks rows {0-3 | 4-7}, bit 4 {r | r+2}, bit 3 {r | r+1}
             const float4 b0 = swap_add32(acc[0], acc[4]), b1 = swap_add32(acc[1], acc[5]);
             const float4 b2 = swap_add32(acc[2], acc[6]), b3 = swap_add32(acc[3], acc[7]);
@@ -400,7 +428,9 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                 }
             }
             rpv = nrpv;
+            g = gn;
         }
+        GNM_GSTAMP(63)
     } else if constexpr (LPR == 2) {
         // ---- 8-float rows (the input layer, F0 <= 8): 2 lanes per neighbour row, 32 neighbours per wave-instruction,
         // GROUPS OF 16 ROWS per wave.  Lane bit 2 is the 16-B chunk; the other five bits number the 32 neighbour slots,
@@ -1394,7 +1424,7 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
 #else
     a.stamps = nullptr;
 #endif
-    size_t lds = (size_t)(n_max + 1) * LPR * 16;
+    size_t lds = (size_t)(n_max + (LPR == 8 ? 2 : 1)) * LPR * 16;      // + the zero row(s)
     const int max_nnz = a.ids_in_lds;             // on entry: largest nnz of the batch (0 = unknown)
     a.ids_in_lds = 0;
     if (LPR == 4 && max_nnz > 0 && lds + (size_t)max_nnz * 2 + 96 <= (size_t)kLdsBudget - 1024) {
@@ -1491,7 +1521,7 @@ extern "C" int gnm_agg_slice_width(int F, int n_max) {
     int fs = 8;
     static const int env_cap = gnm_env_int("GNM_AGG_SLICE_MAX", 128);   // tuning knob: widest slice tried
     while (fs < F && fs < 128 && fs < env_cap) fs <<= 1;
-    while (fs >= 8 && (size_t)(n_max + 1) * fs * 4 + (size_t)(n_max + 2) * 4 + 16 > (size_t)kLdsBudget - 1024) fs >>= 1;
+    while (fs >= 8 && (size_t)(n_max + 2) * fs * 4 + (size_t)(n_max + 2) * 4 + 16 > (size_t)kLdsBudget - 1024) fs >>= 1;
     return fs >= 8 ? fs : 0;
 }
 

@@ -56,6 +56,31 @@ int gnm_csr_transpose(const int32_t* rowptr, const uint16_t* col, int n, int32_t
     return 0;
 }
 
+// Order every CSR row's ids for the 32-float-slice gather (csrc/agg.hip, gnm_agg_kernel<8>): position j of a row wants
+// an EVEN id when (j & 3) < 2 and an ODD one otherwise, as long as the row has both kinds left.  Why: that kernel reads
+// eight neighbour rows of 128 bytes per ds_read_b128; the hardware serves the instruction in 16-lane groups that pair
+// the neighbours at positions (8s, 8s+3), (8s+1, 8s+2), (8s+4, 8s+7), (8s+5, 8s+6), and two 128-byte LDS rows of EQUAL
+// parity lie on the same 32 banks (round 3 PMC: a third of the kernel's LDS cycles were such conflicts).  The edge
+// multiset of a row is unchanged (a sum does not care; graphcnn.py:91-104 fixes no order either) and the relative order
+// inside each parity class is kept.  Every other kernel is indifferent to the order.
+int gnm_csr_parity_order(const int32_t* rowptr, uint16_t* col, int n) {
+    if (n < 0) return -1;
+    std::vector<uint16_t> ev, od;
+    for (int r = 0; r < n; ++r) {
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        if (e - b < 2) continue;
+        ev.clear(); od.clear();
+        for (int32_t k = b; k < e; ++k) (col[k] & 1 ? od : ev).push_back(col[k]);
+        size_t ie = 0, io = 0;
+        for (int32_t k = b; k < e; ++k) {
+            const bool want_odd = ((k - b) & 3) >= 2;
+            const bool take_odd = want_odd ? io < od.size() : ie >= ev.size();
+            col[k] = take_odd ? od[io++] : ev[ie++];
+        }
+    }
+    return 0;
+}
+
 // 1 when A and A^T hold the same edge multiset (then the backward may gather over A itself).
 // Two counting-sort transposes, O(n + E): T1 = A^T and T2 = T1^T = A both come out with sorted rows, so A is
 // symmetric exactly when the two canonical forms are equal (round 1 sorted every row: 1/3 of the 9 ms first touch).

@@ -17,6 +17,7 @@ SIGNATURES = {
     "gnm_debug_device_once": (_i, [_i, _i]),
     "gnm_csr_from_edge_mat": (_i, [_p, _ll, _i, _p, _p]),
     "gnm_csr_transpose": (_i, [_p, _p, _i, _p, _p]),
+    "gnm_csr_parity_order": (_i, [_p, _p, _i]),
     "gnm_csr_is_symmetric": (_i, [_p, _p, _i]),
     "gnm_batch_coo_from_csr": (_ll, [_p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "gnm_agg": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _p, _i, _i, _p, _i, _i, _i, _p, _i, _p, _p]),

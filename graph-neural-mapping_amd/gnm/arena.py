@@ -23,6 +23,8 @@ from ._cabi import GnmError, check, lib
 # benchmark's 30 % 175 / 83 -- the product already wins at the sparsest point measured, which is the threshold.
 # Tuning knob, read once: GNM_DENSE_FILL (a value > 1 turns the matrix-core path off).
 DENSE_MIN_FILL = float(os.environ.get("GNM_DENSE_FILL", "0.04"))
+# GNM_NO_PARITY_ORDER=1: keep every CSR row in edge_mat order (A/B of the id ordering for the 128-byte-row gather)
+PARITY_ORDER = os.environ.get("GNM_NO_PARITY_ORDER") is None
 
 
 class _Growable:
@@ -147,7 +149,13 @@ class GraphArena:
             ct = np.empty(max(E, 1), dtype=np.uint16)
             check(lib.gnm_csr_transpose(rowptr.ctypes.data, col.ctypes.data, n, rpt.ctypes.data, ct.ctypes.data),
                   "gnm_csr_transpose")
-            tr = (rpt, ct[:E])
+            ct = ct[:E]
+            if PARITY_ORDER:
+                check(lib.gnm_csr_parity_order(rpt.ctypes.data, ct.ctypes.data, n), "gnm_csr_parity_order")
+            tr = (rpt, ct)
+        # rows ordered by id parity for the 128-byte-row gather (include/gnm_hip.h gnm_csr_parity_order): same multiset
+        if E and PARITY_ORDER:
+            check(lib.gnm_csr_parity_order(rowptr.ctypes.data, col.ctypes.data, n), "gnm_csr_parity_order")
         return rowptr, col, tr
 
     def add_raw(self, n, edge_mat, feats):

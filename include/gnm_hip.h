@@ -57,6 +57,12 @@ int gnm_csr_from_edge_mat(const int64_t* edge_mat_host, long long E, int n, int3
 int gnm_csr_transpose(const int32_t* rowptr_host, const uint16_t* col_host, int n, int32_t* rowptr_t_host,
                       uint16_t* col_t_host);
 int gnm_csr_is_symmetric(const int32_t* rowptr_host, const uint16_t* col_host, int n);
+/* Order each CSR row's ids for the 32-float-slice gather (gnm_agg with F = 128, n ~ 1000: BASELINE configs[3]): position j
+ * of a row gets an even id when (j & 3) < 2 and an odd one otherwise while the row has both kinds (relative order inside a
+ * parity class kept).  Two 128-byte LDS rows of equal parity share their banks, and the hardware serves a ds_read_b128 in
+ * lane groups that pair positions (8s, 8s+3), (8s+1, 8s+2), (8s+4, 8s+7), (8s+5, 8s+6).  The edge multiset -- all that
+ * Adj_block (graphcnn.py:91-104) fixes -- is unchanged; every other kernel is indifferent to the order.  In place. */
+int gnm_csr_parity_order(const int32_t* rowptr_host, uint16_t* col_host, int n);
 /* Inverse of the above for a whole batch: the reference's Adj_block._indices()
  * (graphcnn.py:91-104), rows grouped by (graph, row).  Used by the parity tests. */
 long long gnm_batch_coo_from_csr(const int32_t* rowptr_arena_host, const uint16_t* col_arena_host,

@@ -90,6 +90,15 @@ def main():
     print("mode %s: launch %.1f us by HIP events (stamped build); workgroup %.0f ticks -> clock <= %.2f GHz" %
           (args.mode, ms * 1e3, wg_ticks.mean(), ghz))
     ng = int(((s[0, 0, 4:60:5] > 0).sum()))
+    if ng == 0:       # the sliced kernel stamps entry / tile loaded / past the barrier / loop left only
+        print("per workgroup (mean over %d workgroups x %d waves):" % (WG, raw.shape[1]))
+        print("  own phase A (tile load + LDS writes)  %6.2f us" % us((s[:, :, 1] - s[:, :, 0]).mean()))
+        print("  barrier wait                           %6.2f us" % us((s[:, :, 3] - s[:, :, 1]).mean()))
+        print("  gather + epilogue + stores             %6.2f us" % us((s[:, :, 63] - s[:, :, 3]).mean()))
+        print("  idle after own last group              %6.2f us" % us((s[:, :, 63].max(1, keepdims=True) - s[:, :, 63]).mean()))
+        print("  workgroup total                        %6.2f us   x %d workgroups / 256 CUs = %.1f us"
+              % (us(wg_ticks.mean()), WG, us(wg_ticks.mean()) * WG / 256))
+        return
     phaseA = us((s[:, :, 1] - s[:, :, 0]).mean())
     drain = us((s[:, :, 2] - s[:, :, 1]).mean())
     barrier = us((s[:, :, 3] - s[:, :, 2]).mean())
