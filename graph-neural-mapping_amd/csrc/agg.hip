@@ -96,6 +96,10 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
     return *(lds_cf4p)(uintptr_t)addr;
 }
 
+typedef __attribute__((address_space(3))) unsigned short* lds_u16p;
+__device__ __forceinline__ unsigned lds_read_u16(unsigned addr) { return *(lds_u16p)(uintptr_t)addr; }
+__device__ __forceinline__ void lds_write_u16(unsigned addr, unsigned v) { *(lds_u16p)(uintptr_t)addr = (unsigned short)v; }
+
 #define GNM_STEP16(S) acc4(acc, lds_read16(row_bcast16<S>(valb) + subb));
 
 // Column id at (uniform base, per-lane 32-bit index): written as base + zero-extended BYTE offset so the load
@@ -341,6 +345,13 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
         // the NEXT group's row bounds and first id chunks are requested in the middle of the current one (one exposed
         // L2 round trip per group before).  A row's own sum does not depend on which wave takes it.
         int* const ticket = rp_s + n + 1;
+        // wave-private id scratch behind the row offsets (8 rows x 64 positions x 2 bytes per wave), when the launcher
+        // found room for it (ids_in_lds == 2)
+        const bool stage8 = p.ids_in_lds == 2;
+        const unsigned scr0 = lds_base + (unsigned)((((size_t)(n + ZR) * (FS * 4) + (size_t)(n + 2) * 4 + 16 + 15) & ~(size_t)15)) +
+                              (unsigned)wave * 1024u;
+        const unsigned scr_w = scr0 + 2u * (unsigned)jlane, scr_r = scr0 + 2u * (unsigned)slot;
+        const unsigned zero_id = (unsigned)(n + ((n ^ (slot >> 1)) & 1));
         int g = wave;
         int rpv = 0;
         unsigned raw[8];
@@ -361,6 +372,23 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
             const float4 self = tile[min(v, n) * LPR + sub];       // ahead of the gather (row n = zeros)
             float4 acc[8];
             int nrpv = 0;
+            unsigned idn[4] = {0u, 0u, 0u, 0u};
+            if (stage8) {
+                // ids through a wave-private LDS scratch (round 4): a lane's id of row r goes to scratch[r][position]
+                // (padding positions: the zero row of the slot's parity), and step S of slot k reads position 8 S + k
+                // back with an immediate offset -- one 2-byte LDS read and one shift-add per step instead of two
+                // bank-masked DPP moves, a zero fill and an add (the kernel is VALU-issue bound: ~35 VALU per row).
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int cnt = min(64, bnd[r + 1] - bnd[r]);
+                    lds_write_u16(scr_w + 128u * r, (jlane < cnt) ? raw[r] : zero_id);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                idn[0] = lds_read_u16(scr_r); idn[1] = lds_read_u16(scr_r + 16u);
+                idn[2] = lds_read_u16(scr_r + 32u); idn[3] = lds_read_u16(scr_r + 48u);
+            }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 if (r == 4) {                                       // the next group's bounds: an LDS read under rows 4-7
@@ -369,7 +397,32 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                 }
                 const int beg = bnd[r], end = bnd[r + 1];
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int e0 = beg; e0 < end; e0 += 64) {
+                int e0 = beg;
+                if (stage8) {
+                    // (every position of the scratch row holds a valid id -- padding = a zero row -- so the first four
+                    //  steps need no guard, and the ids of row r + 1 are requested before row r's rows are waited for:
+                    //  one exposed LDS round trip per row instead of two)
+                    const unsigned rb = scr_r + 128u * r;
+                    const unsigned i0 = idn[0], i1 = idn[1], i2 = idn[2], i3 = idn[3];
+                    if (r < 7) {
+                        idn[0] = lds_read_u16(rb + 128u); idn[1] = lds_read_u16(rb + 144u);
+                        idn[2] = lds_read_u16(rb + 160u); idn[3] = lds_read_u16(rb + 176u);
+                    }
+                    {
+                        const f32x4 t0 = lds_read16((i0 << 7) + subb), t1 = lds_read16((i1 << 7) + subb),
+                                    t2 = lds_read16((i2 << 7) + subb), t3 = lds_read16((i3 << 7) + subb);
+                        acc4(a, (t0 + t1) + (t2 + t3));
+                    }
+                    if (end - beg > 32) {                          // wave-uniform
+                        const unsigned j0 = lds_read_u16(rb + 64u), j1 = lds_read_u16(rb + 80u), j2 = lds_read_u16(rb + 96u),
+                                       j3 = lds_read_u16(rb + 112u);
+                        const f32x4 t0 = lds_read16((j0 << 7) + subb), t1 = lds_read16((j1 << 7) + subb),
+                                    t2 = lds_read16((j2 << 7) + subb), t3 = lds_read16((j3 << 7) + subb);
+                        acc4(a, (t0 + t1) + (t2 + t3));
+                    }
+                    e0 = beg + 64;                                  // (rows of more than 64 neighbours: the chunks below)
+                }
+                for (; e0 < end; e0 += 64) {
                     const int cnt = min(64, end - e0);
                     const unsigned rw = (e0 == beg) ? raw[r] : load_id(cl, 2u * (unsigned)e0 + jl2);
                     const unsigned valb = (jlane < cnt) ? rw * (FS * 4) : zero_row_pad;
@@ -1432,6 +1485,13 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
         lds += (size_t)max_nnz * 2 + 96;          // + alignment shift and 16-B rounding of the staged id block
     } else {
         lds += (size_t)(n_max + 2) * 4 + 16;       // staged row offsets (gnm_agg_slice_width budgets for them)
+        if (LPR == 8) {                             // + the waves' id scratch (16 x 1 KB), where it fits next to the tile
+            const size_t with_scr = ((lds + 15) & ~(size_t)15) + 16 * 1024;
+            if (with_scr <= (size_t)kLdsBudget - 1024 && lds > 48 * 1024) {   // (1024-thread launches only: 16 waves)
+                lds = with_scr;
+                a.ids_in_lds = 2;
+            }
+        }
     }
     GNM_ALLOW_FULL_LDS(&gnm_agg_kernel<LPR>);
     // one workgroup per CU when the tile is large (16 waves to keep the LDS pipe busy);
