@@ -96,6 +96,9 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
     return *(lds_cf4p)(uintptr_t)addr;
 }
 
+typedef unsigned int agg_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const agg_u32x2* lds_cu2p;
+__device__ __forceinline__ agg_u32x2 lds_read_u32x2(unsigned addr) { return *(lds_cu2p)(uintptr_t)addr; }
 typedef __attribute__((address_space(3))) unsigned short* lds_u16p;
 __device__ __forceinline__ unsigned lds_read_u16(unsigned addr) { return *(lds_u16p)(uintptr_t)addr; }
 __device__ __forceinline__ void lds_write_u16(unsigned addr, unsigned v) { *(lds_u16p)(uintptr_t)addr = (unsigned short)v; }
@@ -350,7 +353,10 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
         const bool stage8 = p.ids_in_lds == 2;
         const unsigned scr0 = lds_base + (unsigned)((((size_t)(n + ZR) * (FS * 4) + (size_t)(n + 2) * 4 + 16 + 15) & ~(size_t)15)) +
                               (unsigned)wave * 1024u;
-        const unsigned scr_w = scr0 + 2u * (unsigned)jlane, scr_r = scr0 + 2u * (unsigned)slot;
+        // scratch row layout [slot][step]: the 8 ids a slot reads over the steps of a row are 16 contiguous bytes, so
+        // steps 0-3 (4-7) come with ONE ds_read_b64 each -- eight 2-byte reads per row cost half as many LDS cycles
+        // as the row gather itself (the kernel became LDS-pipe bound once the DPP moves were gone)
+        const unsigned scr_w = scr0 + 2u * (unsigned)((jlane & 7) * 8 + (jlane >> 3)), scr_r = scr0 + 16u * (unsigned)slot;
         const unsigned zero_id = (unsigned)(n + ((n ^ (slot >> 1)) & 1));
         int g = wave;
         int rpv = 0;
@@ -372,7 +378,7 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
             const float4 self = tile[min(v, n) * LPR + sub];       // ahead of the gather (row n = zeros)
             float4 acc[8];
             int nrpv = 0;
-            unsigned idn[4] = {0u, 0u, 0u, 0u};
+            agg_u32x2 idn = {0u, 0u};
             if (stage8) {
                 // ids through a wave-private LDS scratch (round 4): a lane's id of row r goes to scratch[r][position]
                 // (padding positions: the zero row of the slot's parity), and step S of slot k reads position 8 S + k
@@ -386,8 +392,7 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                idn[0] = lds_read_u16(scr_r); idn[1] = lds_read_u16(scr_r + 16u);
-                idn[2] = lds_read_u16(scr_r + 32u); idn[3] = lds_read_u16(scr_r + 48u);
+                idn = lds_read_u32x2(scr_r);
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -403,19 +408,16 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                     //  steps need no guard, and the ids of row r + 1 are requested before row r's rows are waited for:
                     //  one exposed LDS round trip per row instead of two)
                     const unsigned rb = scr_r + 128u * r;
-                    const unsigned i0 = idn[0], i1 = idn[1], i2 = idn[2], i3 = idn[3];
-                    if (r < 7) {
-                        idn[0] = lds_read_u16(rb + 128u); idn[1] = lds_read_u16(rb + 144u);
-                        idn[2] = lds_read_u16(rb + 160u); idn[3] = lds_read_u16(rb + 176u);
-                    }
+                    const unsigned i0 = idn.x & 0xFFFFu, i1 = idn.x >> 16, i2 = idn.y & 0xFFFFu, i3 = idn.y >> 16;
+                    if (r < 7) idn = lds_read_u32x2(rb + 128u);
                     {
                         const f32x4 t0 = lds_read16((i0 << 7) + subb), t1 = lds_read16((i1 << 7) + subb),
                                     t2 = lds_read16((i2 << 7) + subb), t3 = lds_read16((i3 << 7) + subb);
                         acc4(a, (t0 + t1) + (t2 + t3));
                     }
                     if (end - beg > 32) {                          // wave-uniform
-                        const unsigned j0 = lds_read_u16(rb + 64u), j1 = lds_read_u16(rb + 80u), j2 = lds_read_u16(rb + 96u),
-                                       j3 = lds_read_u16(rb + 112u);
+                        const agg_u32x2 jj = lds_read_u32x2(rb + 8u);
+                        const unsigned j0 = jj.x & 0xFFFFu, j1 = jj.x >> 16, j2 = jj.y & 0xFFFFu, j3 = jj.y >> 16;
                         const f32x4 t0 = lds_read16((j0 << 7) + subb), t1 = lds_read16((j1 << 7) + subb),
                                     t2 = lds_read16((j2 << 7) + subb), t3 = lds_read16((j3 << 7) + subb);
                         acc4(a, (t0 + t1) + (t2 + t3));
