@@ -24,9 +24,12 @@ TRUE_SHAPE_FACTOR = 4.0
 # correct fp32 implementations can disagree on a mask bit.  One flipped bit moves
 # a bias-gradient sum by ~1e-3 relative (measured: numpy-fp32 vs numpy-fp64 differ
 # in exactly one mask element of layer 4 -> 9.8e-4 on batch_norms.4.bias, while
-# the reference happened not to flip).  True-shape gradients are therefore
-# compared with the fp64 oracle at 5e-3; the tiny cases keep 5e-5.
-TRUE_SHAPE_GRAD_RTOL = 5e-3
+# the reference happened not to flip).  True-shape gradients of the PRODUCT (the HIP path) are therefore
+# compared at 1e-3 (round 4; 5e-3 until then -- the worst value ever measured on the GPU is 2.4e-4, see
+# profiles/r04_parity_true_shape.md); the tiny cases keep 5e-5.  The numpy-fp32 oracle, a noisier fp32
+# implementation that is test infrastructure and not the product, keeps 5e-3 (ORACLE32_GRAD_RTOL).
+TRUE_SHAPE_GRAD_RTOL = 1e-3
+ORACLE32_GRAD_RTOL = 5e-3
 # A mask bit can also flip between fp32 and fp64 arithmetic as such: in true_s0_eps1_gaverage_naverage the
 # reference and the numpy-fp32 oracle agree with each other to 1e-4 on every gradient but BOTH sit 1.5e-2 from the
 # fp64 oracle (a pre-activation within fp32 rounding of zero: every fp32 implementation takes one side, exact

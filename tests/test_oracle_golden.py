@@ -7,7 +7,7 @@ float32 outputs (it is the build's only fp64 cross-check)."""
 import numpy as np
 import pytest
 
-from helpers import (ORACLE32_FACTOR, RTOL, TRUE_SHAPE_GRAD_RTOL, Calibrated, assert_close, assert_grad_true_shape,
+from helpers import (ORACLE32_FACTOR, ORACLE32_GRAD_RTOL, RTOL, TRUE_SHAPE_GRAD_RTOL, Calibrated, assert_close, assert_grad_true_shape,
                      edge_mat_of, golden_cases, grad_floor,
                      load_case, neighbors_of)
 from oracle import gin_oracle as O
@@ -110,7 +110,8 @@ def test_train_step(case, dtype):
             name = key[len("grad_"):]
             if case.startswith("true_"):
                 assert_grad_true_shape(g[name].reshape(d[key].shape), d[key],
-                                       truth_out["grads"][name].reshape(d[key].shape), what=key, floor=floor)
+                                       truth_out["grads"][name].reshape(d[key].shape), what=key, floor=floor,
+                                       rtol=ORACLE32_GRAD_RTOL if dtype == np.float32 else TRUE_SHAPE_GRAD_RTOL)
             else:
                 assert_close(g[name].reshape(d[key].shape), d[key], rtol=gtol, what=key, floor=floor)
             checked += 1
@@ -118,7 +119,9 @@ def test_train_step(case, dtype):
             assert key[len("gradnone_"):] not in g or not cfg["learn_eps"]
     if "gradproj_r" in d:
         if case.startswith("true_"):
-            gtol = TRUE_SHAPE_GRAD_RTOL
+            # (random projections of the [L H, L H] discriminator gradient cancel heavily: the REFERENCE's own fp32
+            #  value sits 2.7e-3 from the fp64 oracle on the configs[3]-shaped case, so this anchor keeps 5e-3)
+            gtol = ORACLE32_GRAD_RTOL
         W = g["disc.f_k.weight"][0].astype(np.float64)
         assert_close(W @ d["gradproj_r"], d["gradproj_Wr"], rtol=gtol, what="disc dW r")
         assert_close(d["gradproj_s"] @ W, d["gradproj_sW"], rtol=gtol, what="disc s dW")
