@@ -531,7 +531,8 @@ class PackedStaticBatch:
     (gnm/graphs.py CapturedEval): assembling a Batch the general way costs ~15 tiny device ops (~150 us of host
     time), which is most of a B = 1 forward."""
 
-    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False, iso=False, has_bits=False, extra_words=0):
+    def __init__(self, arena, B, n, symmetric, nnz_max, dense=False, iso=False, has_bits=False, extra_words=0,
+                 two_stage=False):
         """extra_words: int64 words appended to the buffer for the caller's own per-batch values (a training step's
         labels and Infomax permutation: gnm/graphs.py), uploaded by the same copy: load_gids(gh, extra)."""
         dev = arena.device
@@ -555,7 +556,10 @@ class PackedStaticBatch:
         # copy queued on the compute stream is a DMA-engine transfer between two replays: it starts when the previous
         # replay has drained and the next one waits for it (~40 us per step measured); from the side stream it passes
         # while the previous step computes.  GNM_PACKED_DIRECT=1: the direct copy (A/B).
-        self._two_stage = dev.type == "cuda" and os.environ.get("GNM_PACKED_DIRECT") is None
+        # Only where a replay is LONG (a whole training step of hundreds of graphs: gnm/graphs.py CapturedTrainStep
+        # asks for it): at one graph per forward the extra stream switch and event cost more host time than the
+        # bubble they remove (0.130 -> 0.148 ms per evaluated graph measured with it everywhere).
+        self._two_stage = bool(two_stage) and dev.type == "cuda" and os.environ.get("GNM_PACKED_DIRECT") is None
         self._side = torch.cuda.Stream(device=dev) if self._two_stage else None
         self._stage_dev = [torch.zeros(words, dtype=torch.int64, device=dev) for _ in self._ring] if self._two_stage else None
         self._done = [None] * len(self._ring)

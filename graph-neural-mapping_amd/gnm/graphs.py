@@ -73,7 +73,8 @@ class CapturedTrainStep:
             self._perm_words = (B + 1) // 2
             self.packed = PackedStaticBatch(arena, B, template_batch.n_max, template_batch.symmetric, nnz_cap,
                                             dense=template_batch.dense, iso=template_batch.iso,
-                                            has_bits=template_batch.has_bits, extra_words=B + self._perm_words)
+                                            has_bits=template_batch.has_bits, extra_words=B + self._perm_words,
+                                            two_stage=B >= 64)
             self.packed.load_gids(gh, self._pack_extra(np.zeros(B, dtype=np.int64), np.arange(B)))
             self.static = self.packed
             self.labels = self.packed.extra[:B]
