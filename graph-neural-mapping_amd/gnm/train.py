@@ -165,10 +165,12 @@ class FusedTrainStep:
 
     capture=True (needs template_batch; every later batch must have its shape) records forward + loss +
     backward (+ Adam when single-rank) into a hipGraph.  With a process group the flat gradient buffer is
-    SUM-all-reduced after the captured part and Adam applies the 1/world factor."""
+    SUM-all-reduced after the captured part and Adam applies the 1/world factor.
+    template_gids (the template batch's arena ids on the host, equal-size graphs): enables run_gids(ids, labels) --
+    the data-loader route: ids, labels and permutation reach the device through one pinned upload (gnm/graphs.py)."""
 
     def __init__(self, model, lr=1e-3, beta=0.05, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 process_group=None, template_batch=None, capture=True):
+                 process_group=None, template_batch=None, capture=True, template_gids=None):
         self.model, self.beta = model, float(beta)
         self.dp = DataParallelGIN(model, process_group)
         if not self.dp.direct:
@@ -186,7 +188,8 @@ class FusedTrainStep:
             opt = self.optimizer
             self.captured = CapturedTrainStep(model, template_batch, self._loss, zero_grad=self.dp.zero_grad,
                                               post_backward=post,
-                                              preserve=(opt.exp_avg, opt.exp_avg_sq, opt.step_count))
+                                              preserve=(opt.exp_avg, opt.exp_avg_sq, opt.step_count),
+                                              gids_host=template_gids)
 
     def _loss(self, c_logit, d_logit, labels):
         loss, self.parts = infomax_loss(c_logit, d_logit, labels, self.beta)
@@ -204,6 +207,16 @@ class FusedTrainStep:
             self.dp.zero_grad()
             c_logit, d_logit = self.model.forward_batch(batch, perm=perm)
             self._loss(c_logit, d_logit, labels).backward()
+            self._allreduce_sum()
+            self.optimizer.step()
+        return self.parts
+
+    def run_gids(self, gids_host, labels_host, perm=None):
+        """run() for a selection given as arena ids + labels on the host (needs template_gids at construction)"""
+        if self.captured is None or self.captured.packed is None:
+            raise RuntimeError("run_gids needs FusedTrainStep(..., capture=True, template_gids=...)")
+        self.captured.run_gids(gids_host, labels_host, perm)
+        if self.dp.world > 1:
             self._allreduce_sum()
             self.optimizer.step()
         return self.parts
