@@ -542,6 +542,364 @@ __global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggm_kernel(const AggArgs
     }
 }
 
+// ---- persistent forward form (round 4; OPT-IN: GNM_AGGM_PERSIST=1) -----------------------------------------------
+// An experiment kept for its measurements; the product launches gnm_aggm_kernel.  The kernel above spends a third of a
+// workgroup's life on its tile load (the ~11 B/clk a CU keeps in flight) and LDS lets only two workgroups per CU overlap
+// their phases.  This form keeps two workgroups per CU RESIDENT and walks each over its units (graph x 32-column block):
+//
+//   B1 | product (all steps) | self term of both row blocks (from the planes)
+//      | the NEXT unit's tile (two items = eight 16-byte loads per lane) and bit rows requested
+//      | epilogue: 16 stores per row block, no loads, no LDS | B0: the planes are dead
+//      | the next unit's tile split into the planes | B1 ...
+//
+// The next tile travels under the epilogue's stores and the wait for the workgroup's slowest wave; nothing is in flight
+// during a product, so the product keeps the register budget it has in gnm_aggm_kernel (116 registers, no scratch).
+// Measured (B = 1024 x n = 400, F = 64, paired with gnm_aggm_kernel in one process): 76.6 us against 70.2 us fused, 77
+// against 69 plain.  What it took to get there, for whoever picks this up:
+//   * a first version split the product at row 256 and kept one item in flight through both halves: 48-72 spilled
+//     registers at the 128 of four waves per SIMD, the reloads (each an s_waitcnt vmcnt(0)) inside the product;
+//   * the unit descriptors have to come through s_load by hand (unit_words below): 84 us with vector loads;
+//   * every wave issues the same number of loads and stores per round, branch-free, or the tile is waited for with
+//     vmcnt(0) -- behind the wave's own stores;
+//   * delaying the CU's second workgroup (HW_ID.TG_ID & 1) by k x 3.6 us so that one multiplies while the other loads:
+//     k = 0..4 -> 76.6, 78, 83, 87, 88 us.  The tile (51 KB a unit) still arrives AFTER the product that hid nothing;
+//     hiding it needs the tile in flight during the product, i.e. 32 more registers or LDS this kernel does not have.
+// Equal units in lockstep lose to the 2048 short workgroups of gnm_aggm_kernel, whose start times the dispatcher
+// staggers by itself.  Forward "sum" forms only (plain and fused BatchNorm + ReLU + readout prologue).
+__global__ void __launch_bounds__(kAggmThreads, 4) gnm_aggp_kernel(const AggArgs p, const int units_total, const int stagger) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // GNM_AGGP_STAGGER: the workgroup in a CU's second slot starts a fraction of a unit late (persistent workgroups with
+    // equal units otherwise run in lockstep: both workgroups of a CU load, multiply and store at the same time)
+    if (__builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4) & 1)      // HW_ID.TG_ID: the workgroup's slot in its CU
+        for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(127);
+    const int nc = p.F >> 5;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const unsigned plane_bytes = (unsigned)(p.n16_max >> 3) * kAggmK8Stride;
+    char* lut = smem + 3u * plane_bytes;
+    float4* rsum = reinterpret_cast<float4*>(lut + 128);
+    const bool pro = p.p_scale != nullptr;
+    const float eps_raw = *(p.eps ? p.eps : p.x);
+    const float cself = p.self_loop ? 1.f : (p.eps ? 1.f + eps_raw : 1.f);
+    if (tid < 16) {          // nibble e -> bf16 (bit 0, bit 1, bit 2, bit 3) as two words
+        const unsigned one = 0x3F80u;
+        u32x2 v;
+        v.x = ((tid & 1) ? one : 0u) | ((tid & 2) ? one << 16 : 0u);
+        v.y = ((tid & 4) ? one : 0u) | ((tid & 8) ? one << 16 : 0u);
+        *reinterpret_cast<u32x2*>(lut + 8 * tid) = v;
+    }
+    // Per-lane constants of the load / split / store phases are re-derived inside the unit loop from a lane number the
+    // compiler cannot see through (an empty asm): hoisted out of the loop they were ~36 registers of offsets kept alive
+    // through the products, and the allocator answered by spilling the bit rows INSIDE the product.
+    auto opaque_lane = [&]() -> int { int L = lane; asm volatile("" : "+v"(L)); return L; };
+
+    // A unit's descriptor words (node_off[b], node_off[b + 1], b_bits_off[b]) through the SCALAR cache, by hand: inside
+    // the unit loop the compiler may not use s_load itself (the loop stores to memory, and nothing tells it that those
+    // stores never hit the descriptors), and as vector loads each of them was a full s_waitcnt vmcnt(0) -- three memory
+    // latencies per unit, the second one draining the tile loads issued just before it.
+    auto unit_words = [&](int b, int& row0, int& n, long long& boff) {
+        unsigned long long w01, wb;
+        const int32_t* pn = p.node_off + b;
+        const int64_t* pb = p.b_bits_off + b;
+        asm volatile("s_load_dwordx2 %0, %2, 0x0\n\ts_load_dwordx2 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(w01), "=&s"(wb) : "s"(pn), "s"(pb) : "memory");
+        row0 = (int)(unsigned)w01; n = (int)(unsigned)(w01 >> 32) - row0; boff = (long long)wb;
+    };
+    // first unit >= `unit` (stride: the grid) that has rows; graphs without nodes get their (empty) readout here
+    auto next_valid = [&](int unit, int& b, int& cb, int& row0, int& n, long long& boff) -> int {
+        for (; unit < units_total; unit += (int)gridDim.x) {
+            const int grp = unit / (8 * nc), within = unit - grp * (8 * nc);
+            b = grp * 8 + (within & 7); cb = within >> 3;
+            if (b >= p.n_graphs) continue;
+            unit_words(b, row0, n, boff);
+            if (n > 0) return unit;
+            if (pro && p.p_gf && tid < 32) p.p_gf[(size_t)b * p.p_ldgf + cb * 32 + tid] = p.p_gf_avg ? 0.f / 0.f : 0.f;
+        }
+        return unit;
+    };
+    // (every per-unit scalar below goes through readfirstlane: they are loop-carried through a loop that contains lane-
+    //  dependent branches, the compiler's divergence analysis then keeps them -- and every address, bound and descriptor
+    //  derived from them -- in vector registers: 174 registers and waterfall loops in the first build of this kernel)
+    // the tile of the unit at (row0, n, col0): item u (0: rows 0-255, 1: rows 256..) = four rows x four columns per lane,
+    // through a buffer descriptor (rows past n read zeros) with 32-bit per-lane offsets
+    float4 v[2][4];
+    const unsigned row_x = (unsigned)p.ldx * 4u;
+    auto load_tile = [&](int L, int row0, int n, int col0) {       // n == 0: a descriptor of no bytes, every load returns zeros
+        const int c4 = (L & 1) | ((L >> 4) << 1), rql = (L >> 1) & 7;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(p.x) + (size_t)row0 * p.ldx + col0, 0, n > 0 ? (int)((((size_t)(n - 1) * p.ldx) + 32) * 4) : 0, 0x00020000);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned lx = (unsigned)((((wave + u * kAggmWaves) << 3) | rql) * 4) * row_x + 16u * (unsigned)c4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                v[u][r] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rx, lx + r * row_x, 0, 0));
+        }
+    };
+    // the prologue's per-column scale and shift of a unit: requested AHEAD of its tile (behind the epilogue's stores they
+    // would be the youngest operation in flight, and the split would wait for every store before it)
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_pro = [&](int L, int col0) {
+        if (pro) {
+            const int c4 = (L & 1) | ((L >> 4) << 1);
+            psc = *reinterpret_cast<const float4*>(p.p_scale + col0 + 4 * c4);
+            psh = *reinterpret_cast<const float4*>(p.p_shift + col0 + 4 * c4);
+        }
+    };
+    auto split_tile = [&](int L, int row0, int n, int n16, int col0) {
+        const int c4 = (L & 1) | ((L >> 4) << 1), rql = (L >> 1) & 7;
+        float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rq = ((wave + u * kAggmWaves) << 3) | rql;
+            if (rq < (n16 >> 2)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 4 * rq + r;
+                    float4 w = row < n ? v[u][r] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pro && row < n) {
+                        w.x = gnm_relu(w.x * psc.x + psh.x); w.y = gnm_relu(w.y * psc.y + psh.y);
+                        w.z = gnm_relu(w.z * psc.z + psh.z); w.w = gnm_relu(w.w * psc.w + psh.w);
+                        if (p.p_hout) *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + row) * p.p_ldh + col0 + 4 * c4) = w;
+                        csum.x += w.x; csum.y += w.y; csum.z += w.z; csum.w += w.w;
+                    }
+                    v[u][r] = w;
+                }
+                const unsigned base = (unsigned)(rq >> 1) * kAggmK8Stride + (unsigned)((4 * c4 * 8 + 4 * (rq & 1)) * 2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    unsigned x0[4], x1[4], x2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float f = c == 0 ? v[u][r].x : (c == 1 ? v[u][r].y : (c == 2 ? v[u][r].z : v[u][r].w));
+                        const unsigned a1 = __float_as_uint(f) & 0xFFFF0000u;
+                        const float r1 = f - __uint_as_float(a1);
+                        const unsigned a2 = __float_as_uint(r1) & 0xFFFF0000u;
+                        const float r2 = r1 - __uint_as_float(a2);
+                        x0[r] = a1; x1[r] = a2; x2[r] = __float_as_uint(r2);
+                    }
+                    u32x2 w0, w1, w2;
+                    w0.x = bf16_pair_hi(x0[0], x0[1]); w0.y = bf16_pair_hi(x0[2], x0[3]);
+                    w1.x = bf16_pair_hi(x1[0], x1[1]); w1.y = bf16_pair_hi(x1[2], x1[3]);
+                    w2.x = bf16_pair_hi(x2[0], x2[1]); w2.y = bf16_pair_hi(x2[2], x2[3]);
+                    char* dst = smem + base + c * 16;
+                    *reinterpret_cast<u32x2*>(dst) = w0;
+                    *reinterpret_cast<u32x2*>(dst + plane_bytes) = w1;
+                    *reinterpret_cast<u32x2*>(dst + 2u * plane_bytes) = w2;
+                }
+            }
+        }
+        if (pro && p.p_gf) {      // readout partials: lanes with the same column chunk (lane bits 1-3 vary), then the waves
+#pragma unroll
+            for (int off = 2; off < 16; off <<= 1) {
+                csum.x += __shfl_xor(csum.x, off, 64); csum.y += __shfl_xor(csum.y, off, 64);
+                csum.z += __shfl_xor(csum.z, off, 64); csum.w += __shfl_xor(csum.w, off, 64);
+            }
+            if (rql == 0) rsum[wave * 8 + c4] = csum;
+        }
+    };
+    unsigned pkA[8], pkB[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pkA[j] = 0u; pkB[j] = 0u; }
+    // this wave's bit rows of graph b (row blocks rbA, rbB; layout: gnm_aggm_kernel), in two requests: the first 16-byte
+    // piece of each half row (steps 0-15) ahead of the product, the second (steps 16-27, 12 bytes) from INSIDE it, at
+    // step 6 -- six registers that would otherwise sit unused through the first sixteen steps, which the allocator
+    // took as its spill candidates (reloaded from scratch at every step of the second half)
+    auto bit_rows = [&](int L, long long boff, int W, int rbA, int rbB, bool two, const u32x4*& ra, const u32x4*& rb) -> int {
+        const int HPW = (((W + 1) >> 1) + 3) & ~3;
+        const uint32_t* gbits = p.adj_bits + boff;
+        const int ii = L & 31, hh = L >> 5;
+        ra = reinterpret_cast<const u32x4*>(gbits + (size_t)(min(rbA, W - 1) * 32 + ii) * (2 * HPW) + hh * HPW);
+        rb = reinterpret_cast<const u32x4*>(gbits + (size_t)((two ? rbB : min(rbA, W - 1)) * 32 + ii) * (2 * HPW) + hh * HPW);
+        return HPW > 4 ? 1 : 0;
+    };
+    auto load_bits_lo = [&](long long b, int W, int rbA, int rbB, bool two) {
+        const u32x4 *ra, *rb;
+        bit_rows(opaque_lane(), b, W, rbA, rbB, two, ra, rb);
+        const u32x4 a0 = ra[0], b0 = rb[0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { pkA[j] = a0[j]; pkB[j] = b0[j]; }
+    };
+    auto load_bits_hi = [&](long long b, int W, int rbA, int rbB, bool two) {
+        const u32x4 *ra, *rb;
+        const int second = bit_rows(opaque_lane(), b, W, rbA, rbB, two, ra, rb);
+        const u32x3 a1 = *reinterpret_cast<const u32x3*>(ra + second), b1 = *reinterpret_cast<const u32x3*>(rb + second);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { pkA[4 + j] = a1[j]; pkB[4 + j] = b1[j]; }
+    };
+    const char* bp0 = smem + h * kAggmK8Stride + i * 16;
+    const char* bp1 = bp0 + plane_bytes;
+    const char* bp2 = bp1 + plane_bytes;
+    f32x16 accA, accB;
+    auto afrag = [&](unsigned pk, int m) -> bf16x8 {
+        const unsigned byte3 = m == 0 ? (pk << 3) : (pk >> (8 * m - 3));
+        const unsigned lo = byte3 & 0x78u, hi = (byte3 >> 4) & 0x78u;
+        const u32x2 l2 = *reinterpret_cast<const u32x2*>(lut + lo);
+        const u32x2 h2 = *reinterpret_cast<const u32x2*>(lut + hi);
+        const u32x4 q = {l2.x, l2.y, h2.x, h2.y};
+        return __builtin_bit_cast(bf16x8, q);
+    };
+    auto bfrag = [&](const char* bp, int ks) -> bf16x8 {
+        return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bp + ks * kAggmStepBytes));
+    };
+    auto product = [&](auto two_tag, int ksteps, long long b, int W, int rbA, int rbB) {   // software-pipelined as in gnm_aggm_kernel
+        constexpr bool TWO = decltype(two_tag)::value;
+        bf16x8 b0 = bfrag(bp0, 0), b1 = bfrag(bp1, 0), b2 = bfrag(bp2, 0);
+        bf16x8 aA = afrag(pkA[0], 0), aB = aA;
+        if constexpr (TWO) aB = afrag(pkB[0], 0);
+#pragma unroll
+        for (int ks = 0; ks < 26; ++ks) {
+            if (ks < ksteps) {                                // wave-uniform
+                if (ks == 6 && ksteps > 16) load_bits_hi(b, W, rbA, rbB, TWO);    // (steps 16.. are its only readers)
+                constexpr int LASTK = 25;
+                const int kn = ks < LASTK ? ks + 1 : LASTK;
+                const bf16x8 n0 = bfrag(bp0, kn), n1 = bfrag(bp1, kn), n2 = bfrag(bp2, kn);
+                const bf16x8 nA = afrag(pkA[kn >> 2], kn & 3);
+                bf16x8 nB = nA;
+                if constexpr (TWO) nB = afrag(pkB[kn >> 2], kn & 3);
+                __builtin_amdgcn_sched_barrier(0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b0, accA, 0, 0, 0);
+                if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b0, accB, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b1, accA, 0, 0, 0);
+                if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b1, accB, 0, 0, 0);
+                accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aA, b2, accA, 0, 0, 0);
+                if constexpr (TWO) accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aB, b2, accB, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                b0 = n0; b1 = n1; b2 = n2; aA = nA; aB = nB;
+            }
+        }
+    };
+    // acc += cself x (the tile's own values of row block rb): the planes add up to them exactly
+    auto selfadd = [&](f32x16& acc, int rb, int n16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const char* e = smem + (unsigned)min(rb * 4 + k, (n16 >> 3) - 1) * kAggmK8Stride + i * 16 + h * 8;
+            const u32x2 p1 = *reinterpret_cast<const u32x2*>(e);
+            const u32x2 p2 = *reinterpret_cast<const u32x2*>(e + plane_bytes);
+            const u32x2 p3 = *reinterpret_cast<const u32x2*>(e + 2u * plane_bytes);
+            const bool in_tile = rb * 4 + k < (n16 >> 3);
+            const float w0 = (__uint_as_float(p1.x << 16) + __uint_as_float(p2.x << 16)) + __uint_as_float(p3.x << 16);
+            const float w1 = (__uint_as_float(p1.x & 0xFFFF0000u) + __uint_as_float(p2.x & 0xFFFF0000u)) + __uint_as_float(p3.x & 0xFFFF0000u);
+            const float w2 = (__uint_as_float(p1.y << 16) + __uint_as_float(p2.y << 16)) + __uint_as_float(p3.y << 16);
+            const float w3 = (__uint_as_float(p1.y & 0xFFFF0000u) + __uint_as_float(p2.y & 0xFFFF0000u)) + __uint_as_float(p3.y & 0xFFFF0000u);
+            acc[4 * k + 0] = fmaf(cself, in_tile ? w0 : 0.f, acc[4 * k + 0]);
+            acc[4 * k + 1] = fmaf(cself, in_tile ? w1 : 0.f, acc[4 * k + 1]);
+            acc[4 * k + 2] = fmaf(cself, in_tile ? w2 : 0.f, acc[4 * k + 2]);
+            acc[4 * k + 3] = fmaf(cself, in_tile ? w3 : 0.f, acc[4 * k + 3]);
+        }
+    };
+
+    // ---- the first unit ---------------------------------------------------------------------------------------------
+    int b, cb, row0, n;
+    long long boff;
+    int unit = next_valid((int)blockIdx.x, b, cb, row0, n, boff);
+    if (unit >= units_total) return;
+    int col0 = cb * 32;
+    load_pro(opaque_lane(), col0);
+    load_tile(opaque_lane(), row0, n, col0);
+    {
+        const int W = (n + 31) >> 5, role = (wave + cb) % kAggmWaves;
+        __builtin_amdgcn_sched_barrier(0);
+        load_bits_lo(boff, W, role, role + kAggmWaves, role + kAggmWaves < W);
+    }
+    split_tile(opaque_lane(), row0, n, ((n + 15) >> 4) * 16, col0);
+    __syncthreads();                                                             // B1 of the first unit
+
+    while (true) {                                                               // workgroup-uniform
+        const int W = (n + 31) >> 5;
+        const int ksteps = (n + 15) >> 4;
+        const int n16 = ksteps * 16;
+        const int role = (wave + cb) % kAggmWaves;
+        const int rbA = role, rbB = role + kAggmWaves;
+        const bool two = rbB < W;
+        const bool has_rows = rbA < W;
+        if (pro && p.p_gf && tid < 8) {      // (the shares were written before B1; the next ones come after B0)
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int w = 0; w < kAggmWaves; ++w) {
+                const float4 s = rsum[w * 8 + tid];
+                t.x += s.x; t.y += s.y; t.z += s.z; t.w += s.w;
+            }
+            if (p.p_gf_avg) {
+                const float inv = 1.f / (float)n;
+                t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+            }
+            *reinterpret_cast<float4*>(p.p_gf + (size_t)b * p.p_ldgf + col0 + 4 * tid) = t;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_rows) {
+            if (two) {
+                product(std::true_type{}, ksteps, boff, W, rbA, rbB);
+                __builtin_amdgcn_sched_barrier(0);
+                selfadd(accB, rbB, n16);
+            } else {
+                product(std::false_type{}, ksteps, boff, W, rbA, rbB);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(pkB[j]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            selfadd(accA, rbA, n16);
+        } else {
+            // (a wave "uses" the bit rows it requested on the paths that do not need them, here and above: left pending,
+            //  they made the compiler guard the next round's first writes to those registers with a wait that the
+            //  scale/shift loads -- a memory latency in front of the epilogue's stores -- had to satisfy)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(pkA[j]), "v"(pkB[j]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // The next unit: its tile and bit rows travel under the epilogue and the wait for the slowest wave.  Both the
+        // loads and the stores below are issued by EVERY wave in EVERY round (a workgroup without a next unit loads
+        // through an empty descriptor, a wave without a row block stores past the end of its descriptor: the hardware
+        // drops both), so that the number of memory operations between a tile load and its use does not depend on a
+        // branch -- with the branches the compiler had to wait for the tile with s_waitcnt vmcnt(0), i.e. until this
+        // wave's own stores had drained as well.
+        int nb = b, ncb = cb, nrow0 = row0, nn = 0;
+        long long nboff = boff;
+        const int nunit = next_valid(unit + (int)gridDim.x, nb, ncb, nrow0, nn, nboff);
+        const bool more = nunit < units_total;
+        if (!more) nn = 0;
+        const int ncol0 = ncb * 32;
+        if (ncb != cb) load_pro(opaque_lane(), ncol0);        // (the grid is a multiple of 8 nc for every nc that divides 64: rare)
+        load_tile(opaque_lane(), nrow0, nn, ncol0);
+        {
+            const int nW = more ? (nn + 31) >> 5 : W, nrole = (wave + ncb) % kAggmWaves;
+            load_bits_lo(nboff, nW, nrole, nrole + kAggmWaves, nrole + kAggmWaves < nW);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned ybytes = (unsigned)(((size_t)(n - 1) * p.ldy + p.F) * 4);
+            const __amdgpu_buffer_rsrc_t ry =
+                __builtin_amdgcn_make_buffer_rsrc(p.y + (size_t)row0 * p.ldy, 0, (int)ybytes, 0x00020000);
+            const unsigned row_y = (unsigned)p.ldy * 4u;
+            const int Ly = opaque_lane();
+            const unsigned lane_y = (unsigned)((4 * (Ly >> 5) * p.ldy + col0 + (Ly & 31)) * 4);
+            const unsigned yA = has_rows ? lane_y + (unsigned)(rbA * 32) * row_y : 0x80000000u;
+            const unsigned yB = two ? lane_y + (unsigned)(rbB * 32) * row_y : 0x80000000u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accA[4 * k + q]), ry, yA + (unsigned)(8 * k + q) * row_y, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accB[4 * k + q]), ry, yB + (unsigned)(8 * k + q) * row_y, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!more) break;
+        unit = nunit; b = nb; cb = ncb; row0 = nrow0; n = nn; col0 = ncol0; boff = nboff;
+        __syncthreads();                                                         // B0: every wave is through with the planes
+        __builtin_amdgcn_sched_barrier(0);
+        split_tile(opaque_lane(), row0, n, ((n + 15) >> 4) * 16, col0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                                         // B1
+    }
+}
+
 // ---- bit adjacency ----------------------------------------------------------------------------
 // graph g: W = ceil(n / 32) bit words per row = 4 W bytes; byte j of a row holds columns 8 j .. 8 j + 7 (bit k % 8 of
 // byte k / 8 = 1 iff k is in row v of the CSR).  The bytes are stored DE-INTERLEAVED: even bytes (j = 2 s: the first 8
@@ -608,6 +966,19 @@ static bool aggm_shape_ok(const AggArgs& a, int n_max) {
     return true;
 }
 
+static bool aggm_persist() { static const bool v = gnm_env_int("GNM_AGGM_PERSIST", 0) != 0; return v; }
+static int aggm_cu_count() {          // per device, asked once
+    static int cus[kGnmMaxDevices] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kGnmMaxDevices) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
 static int launch_aggm(AggArgs a, int B, int n_max, bool stats, hipStream_t stream) {
 #ifdef GNM_AGG16_TUNING
     a.stamps = g_aggm_stamps;
@@ -624,6 +995,18 @@ static int launch_aggm(AggArgs a, int B, int n_max, bool stats, hipStream_t stre
         GNM_ALLOW_FULL_LDS((&gnm_aggm_kernel<S_, A_>));                                                      \
         hipLaunchKernelGGL((gnm_aggm_kernel<S_, A_>), dim3(grid), dim3(kAggmThreads), lds, stream, a);       \
     } while (0)
+    // opt-in experiment (GNM_AGGM_PERSIST=1; slower than the launches below, see gnm_aggp_kernel): forward "sum" forms
+    // on two resident workgroups per CU walking the units (one per CU where a plane set is too large for two)
+    if (aggm_persist() && !stats && !a.average && !a.backward && !a.deps_partial && a.F >= 32 && a.y) {
+        const int per_cu = 2 * lds <= (size_t)kLdsBudget ? 2 : 1;
+        int pgrid = aggm_cu_count() * per_cu;
+        if (pgrid > grid) pgrid = grid;
+        GNM_ALLOW_FULL_LDS((&gnm_aggp_kernel));
+        static const int stagger = gnm_env_int("GNM_AGGP_STAGGER", 0);      // x 3.6 us (s_sleep 127 at 2.25 GHz)
+        hipLaunchKernelGGL(gnm_aggp_kernel, dim3(pgrid), dim3(kAggmThreads), lds, stream, a, grid, per_cu == 2 ? stagger : 0);
+        GNM_CHECK_LAUNCH();
+        return GNM_OK;
+    }
     if (a.F < 32) {
         GNM_ALLOW_FULL_LDS((&gnm_aggm_kernel<false, true, true>));
         GNM_ALLOW_FULL_LDS((&gnm_aggm_kernel<false, false, true>));

@@ -2,6 +2,8 @@
 against the fp64 restatement of graphcnn.py:154-161 / 178-182 at the library's fp32 tolerance (1e-5 relative, max
 norm), against the CSR gather kernels it stands in for (same fused forms, same outputs), and its own invariants
 (bit matrix == adjacency, refusals, run-to-run determinism)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -355,3 +357,18 @@ def test_dense_routing_of_isolated_nodes():
             spec = core.GinSpec(2, 2, learn_eps, "sum", npool)
             assert core._dense(full, 64, spec)
             assert core._dense(iso, 64, spec) == (not (npool == "average" and learn_eps))
+
+
+@pytest.mark.gpu
+def test_persistent_forward_form_opt_in():
+    """GNM_AGGM_PERSIST=1 (csrc/aggm.hip, gnm_aggp_kernel: an experiment the product does not launch -- measured slower)
+    still computes the same forward: the forward tests of this file once more in ONE child process with the knob set
+    (the library reads it once, at its first launch)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GNM_AGGM_PERSIST="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_aggm_forward_backward or test_aggm_forward_with_fused_bn_relu_readout"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-1500:]
