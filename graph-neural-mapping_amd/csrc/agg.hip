@@ -112,10 +112,19 @@ __device__ __forceinline__ unsigned load_id(const uint16_t* base, unsigned byte_
     return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
-template <int LPR>
+// MODE (32-float slices, LPR == 8, only; round 4 -- what gnm_agg16_kernel does for the 64-wide shape):
+//   1 = forward PROLOGUE: x is the Z of the layer below's last Linear; the tile load applies that layer's outer
+//       BatchNorm + ReLU (p_scale / p_shift), writes the activation (p_hout, optional) and the graph readout (p_gf):
+//       gnm_bn_relu_readout's pass (45 us of 128-wide rows at configs[3]) rides on loads this kernel issues anyway;
+//   2 = backward STATS: the epilogue adds the readout / discriminator terms, applies the ReLU mask of the layer
+//       below and reduces that layer's BatchNorm-backward column sums (s_partial), and takes d eps from the rows it
+//       holds (h recomputed from sZ): gnm_bn_relu_bwd_stats's pass (75 us) and the hfwd read of phase A go away.
+template <int LPR, int MODE = 0>
 __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     constexpr int FS = LPR * 4;        // floats per LDS row
     constexpr int SLOTS = 64 / LPR;    // neighbour rows read per wave-instruction
+    constexpr bool PRO = MODE == 1, STATS = MODE == 2;
+    static_assert(MODE == 0 || LPR == 8, "fused forms: 32-float slices only");
 #ifdef GNM_AGG16_TUNING       // in-kernel timeline (tools/agg_timeline.py)
 #define GNM_GSTAMP(k)                                                                                         \
     if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
@@ -145,9 +154,26 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     // ---- phase A: HBM -> LDS, coalesced; optional 1/deg pre-scale and d-eps dot ----
     double dot = 0.0;
     int i0 = tid;
+    // d eps: dot(x, hfwd) on the way in, or -- STATS launches without hfwd -- from the rows the epilogue holds.  The
+    // launcher only starts the fused forms on full-width, 16-byte addressable slices, and a thread keeps the column
+    // chunk tid & (LPR - 1) for all its rows (the workgroup size is a multiple of LPR).
+    const bool dot_a = p.deps_partial && (!STATS || p.hfwd);
+    float4 psc = make_float4(1.f, 1.f, 1.f, 1.f), psh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (PRO) {
+        psc = *reinterpret_cast<const float4*>(p.p_scale + col0 + 4 * (tid & (LPR - 1)));
+        psh = *reinterpret_cast<const float4*>(p.p_shift + col0 + 4 * (tid & (LPR - 1)));
+    }
+    auto prologue = [&](int i, float4 w) -> float4 {      // (PRO) the activation of tile element i, written and summed
+        w.x = gnm_relu(w.x * psc.x + psh.x); w.y = gnm_relu(w.y * psc.y + psh.y);
+        w.z = gnm_relu(w.z * psc.z + psh.z); w.w = gnm_relu(w.w * psc.w + psh.w);
+        if (p.p_hout) *reinterpret_cast<float4*>(p.p_hout + (size_t)(row0 + i / LPR) * p.p_ldh + col0 + 4 * (i & (LPR - 1))) = w;
+        csum.x += w.x; csum.y += w.y; csum.z += w.z; csum.w += w.w;
+        return w;
+    };
     // full-width, 16-byte addressable slices: 8 x 16 B per thread in flight (the loop below issues ONE load per trip,
     // inside a lane-dependent branch, i.e. one memory round trip per 16 KB of the tile: 16-32 us of a 128 KB tile)
-    if (vec_in && col0 + FS <= p.F && (!p.deps_partial || vec_h)) {       // wave-uniform
+    if (vec_in && col0 + FS <= p.F && (!dot_a || vec_h)) {       // wave-uniform
         constexpr int UA = 8;
         const int total = n * LPR;
         for (; i0 + (UA - 1) * nthreads < total; i0 += UA * nthreads) {
@@ -158,7 +184,7 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                 const int r = i / LPR, c = i - r * LPR;
                 v[u] = *reinterpret_cast<const float4*>(p.x + (size_t)(row0 + r) * p.ldx + col0 + 4 * c);
             }
-            if (p.deps_partial) {
+            if (dot_a) {
 #pragma unroll
                 for (int u = 0; u < UA; ++u) {
                     const int i = i0 + u * nthreads;
@@ -176,6 +202,7 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                     const float d = (float)(drp[r + 1] - drp[r] + p.self_loop);
                     w.x /= d; w.y /= d; w.z /= d; w.w /= d;
                 }
+                if constexpr (PRO) w = prologue(i, w);
                 tile[i] = w;
             }
         }
@@ -194,7 +221,7 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
             v.z = (cc + 2 < p.F) ? src[2] : 0.f;
             v.w = (cc + 3 < p.F) ? src[3] : 0.f;
         }
-        if (p.deps_partial) {
+        if (dot_a) {
             const float* hs = p.hfwd + (size_t)(row0 + r) * p.ldh + cc;
             float4 h;
             if (vec_h && cc + 3 < p.F) {
@@ -211,6 +238,7 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
             const float d = (float)(drp[r + 1] - drp[r] + p.self_loop);
             v.x /= d; v.y /= d; v.z /= d; v.w /= d;
         }
+        if constexpr (PRO) v = prologue(i, v);
         tile[i] = v;
     }
     constexpr int ZR = LPR == 8 ? 2 : 1;       // zero rows behind the tile (LPR == 8: one of each parity, see phase B)
@@ -221,10 +249,35 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
     if (stage_rp)
         for (int i = tid; i <= n; i += nthreads) rp_s[i] = rp[i];
     if (LPR == 8 && tid == 0) rp_s[n + 1] = nthreads >> 6;      // the group ticket (phase B): every wave's first group is its own number
+    // LDS behind the row offsets (LPR == 8): the waves' id scratch (16 x 1 KB, ids_in_lds == 2), then the prologue's
+    // readout shares ([waves][8] float4)
+    const size_t scr_off = ((size_t)(n + ZR) * (FS * 4) + (size_t)(n + 2) * 4 + 16 + 15) & ~(size_t)15;
+    float4* const rsum = reinterpret_cast<float4*>(smem + scr_off + (p.ids_in_lds == 2 ? 16 * 1024 : 0));
+    if constexpr (PRO) {
+        if (p.p_gf) {      // the 8 lanes of a wave that share a column chunk (lane bits 3-5), then the waves (below)
+#pragma unroll
+            for (int off = 8; off < 64; off <<= 1) {
+                csum.x += __shfl_xor(csum.x, off, 64); csum.y += __shfl_xor(csum.y, off, 64);
+                csum.z += __shfl_xor(csum.z, off, 64); csum.w += __shfl_xor(csum.w, off, 64);
+            }
+            if ((tid & 63) < 8) rsum[(tid >> 6) * 8 + (tid & 7)] = csum;
+        }
+    }
     GNM_GSTAMP(1)
     GNM_GSTAMP(2)
     __syncthreads();
     GNM_GSTAMP(3)
+    if constexpr (PRO) {
+        if (p.p_gf && tid < 8) {      // graph readout of the activation just formed (graphcnn.py:229), in wave order
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int w = 0; w < (nthreads >> 6); ++w) acc4(t, rsum[w * 8 + tid]);
+            if (p.p_gf_avg) {
+                const float inv = 1.f / (float)n;
+                t.x *= inv; t.y *= inv; t.z *= inv; t.w *= inv;
+            }
+            *reinterpret_cast<float4*>(p.p_gf + (size_t)b * p.p_ldgf + col0 + 4 * tid) = t;
+        }
+    }
 
     // ---- phase B, narrow features (FS <= 16 floats): one THREAD per (row, 16-B chunk) ------
     // The rows are so short that the wave-cooperative scheme below spends its time in
@@ -351,8 +404,7 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
         // wave-private id scratch behind the row offsets (8 rows x 64 positions x 2 bytes per wave), when the launcher
         // found room for it (ids_in_lds == 2)
         const bool stage8 = p.ids_in_lds == 2;
-        const unsigned scr0 = lds_base + (unsigned)((((size_t)(n + ZR) * (FS * 4) + (size_t)(n + 2) * 4 + 16 + 15) & ~(size_t)15)) +
-                              (unsigned)wave * 1024u;
+        const unsigned scr0 = lds_base + (unsigned)scr_off + (unsigned)wave * 1024u;
         // scratch row layout [slot][step]: the 8 ids a slot reads over the steps of a row are 16 contiguous bytes, so
         // steps 0-3 (4-7) come with ONE ds_read_b64 each -- eight 2-byte reads per row cost half as many LDS cycles
         // as the row gather itself (the kernel became LDS-pipe bound once the DPP moves were gone)
@@ -368,14 +420,43 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) raw[r] = load_id(cl, 2u * (unsigned)__builtin_amdgcn_readlane(rpv, r) + jl2);
         }
+        // STATS: per-lane column sums of the rows this lane group ends up owning, and the per-column constants of the
+        // layer below (chunk `sub` of this slice).  The deal of groups is STATIC there (wave, wave + W, ...): the sums
+        // are accumulated per wave, and with tickets their order -- hence their last bits -- would change from launch
+        // to launch (every reduction of this library has a fixed order).
+        float4 ss1 = make_float4(0.f, 0.f, 0.f, 0.f), ss2 = ss1, s_pb = ss1, s_ub = ss1;
+        float4 lsc = ss1, lsh = ss1, lmu = ss1;
+        if constexpr (STATS) {
+            lsc = *reinterpret_cast<const float4*>(p.s_scale + col0 + 4 * sub);
+            lsh = *reinterpret_cast<const float4*>(p.s_shift + col0 + 4 * sub);
+            lmu = *reinterpret_cast<const float4*>(p.s_mean + col0 + 4 * sub);    // (rstd multiplies the column sums at the end)
+            if (p.s_dpool) {
+                s_pb = *reinterpret_cast<const float4*>(p.s_dpool + (size_t)b * p.ld_dpool + col0 + 4 * sub);
+                if (p.s_avg) {
+                    const float w = 1.0f / (float)n;
+                    s_pb.x *= w; s_pb.y *= w; s_pb.z *= w; s_pb.w *= w;
+                }
+            }
+            if (p.s_dsc1) s_ub = *reinterpret_cast<const float4*>(p.s_U + (size_t)b * p.ld_U + col0 + 4 * sub);
+        }
         while (g < ngroups) {                                       // wave-uniform
-            int gn = 0;
-            if (lane == 0) gn = atomicAdd(ticket, 1);                // (read after the first four rows)
+            int gn = g + nwaves;
+            if constexpr (!STATS) {
+                gn = 0;
+                if (lane == 0) gn = atomicAdd(ticket, 1);            // (read after the first four rows)
+            }
             int bnd[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) bnd[i] = __builtin_amdgcn_readlane(rpv, i);
             const int v = 8 * g + slot;
             const float4 self = tile[min(v, n) * LPR + sub];       // ahead of the gather (row n = zeros)
+            float4 zrow = make_float4(0.f, 0.f, 0.f, 0.f);
+            float dsc_v = 0.f;
+            if constexpr (STATS) {     // requested ahead of the gather, consumed in the epilogue
+                const int vc = row0 + min(v, n - 1);
+                zrow = *reinterpret_cast<const float4*>(p.sZ + (size_t)vc * p.ldsz + col0 + 4 * sub);
+                if (p.s_dsc1) dsc_v = p.s_dsc1[vc];
+            }
             float4 acc[8];
             int nrpv = 0;
             agg_u32x2 idn = {0u, 0u};
@@ -470,6 +551,32 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
                         sb.w = (cc + 3 < p.F) ? src[3] : 0.f;
                     }
                     tot.x += selfB * sb.x; tot.y += selfB * sb.y; tot.z += selfB * sb.z; tot.w += selfB * sb.w;
+                    if constexpr (STATS) {
+                        if (p.deps_partial && !p.hfwd) {
+                            // d eps += dpooled[v] . h[v], h = relu(bn_lo(Z[v])) recomputed as the forward formed it
+                            const float hx = gnm_relu(zrow.x * lsc.x + lsh.x), hy = gnm_relu(zrow.y * lsc.y + lsh.y);
+                            const float hz = gnm_relu(zrow.z * lsc.z + lsh.z), hw = gnm_relu(zrow.w * lsc.w + lsh.w);
+                            dot += (double)(sb.x * hx + sb.y * hy) + (double)(sb.z * hz + sb.w * hw);
+                        }
+                    }
+                }
+                if constexpr (STATS) {
+                    // total gradient at this layer output = aggregation backward + readout + discriminator terms
+                    tot.x += s_pb.x + dsc_v * s_ub.x; tot.y += s_pb.y + dsc_v * s_ub.y;
+                    tot.z += s_pb.z + dsc_v * s_ub.z; tot.w += s_pb.w + dsc_v * s_ub.w;
+                    if (p.s_dsc1 && row0 + v < p.n_batch) {     // rows perm[g] < B of the shuffled branch (graphcnn.py:242)
+                        const int gq = gnm_perm_entry(p.s_inv_perm[row0 + v], p.n_batch);
+                        const float s2 = p.s_s2sum[gq];
+                        const float4 uq = *reinterpret_cast<const float4*>(p.s_U + (size_t)gq * p.ld_U + col0 + 4 * sub);
+                        tot.x += s2 * uq.x; tot.y += s2 * uq.y; tot.z += s2 * uq.z; tot.w += s2 * uq.w;
+                    }
+                    if (!(zrow.x * lsc.x + lsh.x > 0.f)) tot.x = 0.f;
+                    if (!(zrow.y * lsc.y + lsh.y > 0.f)) tot.y = 0.f;
+                    if (!(zrow.z * lsc.z + lsh.z > 0.f)) tot.z = 0.f;
+                    if (!(zrow.w * lsc.w + lsh.w > 0.f)) tot.w = 0.f;
+                    ss1.x += tot.x; ss1.y += tot.y; ss1.z += tot.z; ss1.w += tot.w;
+                    ss2.x += tot.x * (zrow.x - lmu.x); ss2.y += tot.y * (zrow.y - lmu.y);
+                    ss2.z += tot.z * (zrow.z - lmu.z); ss2.w += tot.w * (zrow.w - lmu.w);
                 }
                 float* dst = p.y + (size_t)(row0 + v) * p.ldy + cc;
                 if (vec_out && col0 + FS <= p.F) {          // wave-uniform: ONE 16-byte store per lane (see agg16)
@@ -486,6 +593,31 @@ __global__ void __launch_bounds__(1024) gnm_agg_kernel(const AggArgs p) {
             g = gn;
         }
         GNM_GSTAMP(63)
+        if constexpr (STATS) {     // column sums: the 8 lane groups of a wave, then the waves, in a fixed order
+            __syncthreads();        // (everyone is done reading the tile: its first bytes are reused)
+            double* sred = reinterpret_cast<double*>(smem) + 64;      // [nwaves][2][32] (after the d-eps slots)
+            const float v1[4] = {ss1.x, ss1.y, ss1.z, ss1.w}, v2[4] = {ss2.x, ss2.y, ss2.z, ss2.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                double d1 = (double)v1[c], d2 = (double)v2[c];
+#pragma unroll
+                for (int off = 8; off < 64; off <<= 1) {
+                    d1 += __shfl_xor(d1, off, 64); d2 += __shfl_xor(d2, off, 64);
+                }
+                if (lane < 8) {
+                    sred[(wave * 2 + 0) * 32 + 4 * sub + c] = d1;
+                    sred[(wave * 2 + 1) * 32 + 4 * sub + c] = d2;
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int which = tid >> 5, col = tid & 31;
+                double sum = 0.0;
+                for (int w = 0; w < nwaves; ++w) sum += sred[(w * 2 + which) * 32 + col];
+                if (which) sum *= (double)p.s_rstd[col0 + col];      // sum G (Z - mean) -> sum G xhat
+                p.s_partial[((size_t)b * 2 + which) * p.F + col0 + col] = sum;
+            }
+        }
     } else if constexpr (LPR == 2) {
         // ---- 8-float rows (the input layer, F0 <= 8): 2 lanes per neighbour row, 32 neighbours per wave-instruction,
         // GROUPS OF 16 ROWS per wave.  Lane bit 2 is the 16-B chunk; the other five bits number the 32 neighbour slots,
@@ -1482,6 +1614,9 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
     size_t lds = (size_t)(n_max + (LPR == 8 ? 2 : 1)) * LPR * 16;      // + the zero row(s)
     const int max_nnz = a.ids_in_lds;             // on entry: largest nnz of the batch (0 = unknown)
     a.ids_in_lds = 0;
+    const int mode = LPR == 8 ? (a.sZ ? 2 : (a.p_scale ? 1 : 0)) : 0;      // fused forms (gnm_agg_kernel's MODE)
+    if (LPR != 8 && (a.sZ || a.p_scale)) return GNM_ERR_UNSUPPORTED;
+    const size_t extra = mode == 1 ? 16 * 8 * 16 : 0;                      // prologue: [16 waves][8] float4 of readout shares
     if (LPR == 4 && max_nnz > 0 && lds + (size_t)max_nnz * 2 + 96 <= (size_t)kLdsBudget - 1024) {
         a.ids_in_lds = 1;
         lds += (size_t)max_nnz * 2 + 96;          // + alignment shift and 16-B rounding of the staged id block
@@ -1489,11 +1624,15 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
         lds += (size_t)(n_max + 2) * 4 + 16;       // staged row offsets (gnm_agg_slice_width budgets for them)
         if (LPR == 8) {                             // + the waves' id scratch (16 x 1 KB), where it fits next to the tile
             const size_t with_scr = ((lds + 15) & ~(size_t)15) + 16 * 1024;
-            if (with_scr <= (size_t)kLdsBudget - 1024 && lds > 48 * 1024) {   // (1024-thread launches only: 16 waves)
+            if (with_scr + extra <= (size_t)kLdsBudget - 1024 && lds > 48 * 1024) {   // (1024-thread launches only: 16 waves)
                 lds = with_scr;
                 a.ids_in_lds = 2;
             }
         }
+    }
+    if (extra) {
+        lds = ((lds + 15) & ~(size_t)15) + extra;
+        if (lds > (size_t)kLdsBudget - 1024) return GNM_ERR_UNSUPPORTED;
     }
     GNM_ALLOW_FULL_LDS(&gnm_agg_kernel<LPR>);
     // one workgroup per CU when the tile is large (16 waves to keep the LDS pipe busy);
@@ -1505,6 +1644,22 @@ static int launch_agg(const AggArgs& a0, int B, int n_max, hipStream_t stream) {
         threads = ((n_max * LPR + 63) / 64) * 64;
         if (threads > 1024) threads = 1024;
         if (threads < 256) threads = 256;
+    }
+    if constexpr (LPR == 8) {
+        if (mode) {
+            // the STATS reductions at the end reuse the tile's first bytes: [64] d-eps slots + [waves][2][32] doubles
+            const size_t red = (size_t)(64 + (threads / 64) * 64) * 8;
+            if (lds < red) lds = red;
+            if (mode == 1) {
+                GNM_ALLOW_FULL_LDS((&gnm_agg_kernel<8, 1>));
+                hipLaunchKernelGGL((gnm_agg_kernel<8, 1>), dim3(B * a.nslices), dim3(threads), lds, stream, a);
+            } else {
+                GNM_ALLOW_FULL_LDS((&gnm_agg_kernel<8, 2>));
+                hipLaunchKernelGGL((gnm_agg_kernel<8, 2>), dim3(B * a.nslices), dim3(threads), lds, stream, a);
+            }
+            GNM_CHECK_LAUNCH();
+            return GNM_OK;
+        }
     }
     hipLaunchKernelGGL(gnm_agg_kernel<LPR>, dim3(B * a.nslices), dim3(threads), lds, stream, a);
     GNM_CHECK_LAUNCH();
@@ -1641,8 +1796,13 @@ extern "C" int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, con
                                  int ld_U, const int32_t* inv_perm, const float* s2sum, double* s_partial,
                                  void* stream) {
     if (B <= 0) return GNM_OK;
-    if (F != 64 || gnm_agg_slice_width(F, n_max) != 64 || !y || !sZ || !s_partial) return GNM_ERR_UNSUPPORTED;
-    if ((ldsz & 3) || (ldy & 3) || (dpool && (ld_dpool & 3)) || (dsc1 && (ld_U & 3))) return GNM_ERR_UNSUPPORTED;
+    // two shapes: one 64-wide slice (gnm_agg16_kernel), or 32-float slices of a width that is a multiple of 32
+    // (gnm_agg_kernel<8, 2>: hidden_dim 128 on graphs too large for a wider slice, configs[3])
+    const int fs = gnm_agg_slice_width(F, n_max);
+    const bool wide64 = F == 64 && fs == 64, sliced32 = fs == 32 && (F & 31) == 0;
+    if ((!wide64 && !sliced32) || !y || !sZ || !s_partial) return GNM_ERR_UNSUPPORTED;
+    if ((ldsz & 3) || (ldy & 3) || (ldx & 3) || (dpool && (ld_dpool & 3)) || (dsc1 && (ld_U & 3))) return GNM_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(x) & 15) return GNM_ERR_UNSUPPORTED;
     const uintptr_t al = reinterpret_cast<uintptr_t>(sZ) | reinterpret_cast<uintptr_t>(s_scale) |
                          reinterpret_cast<uintptr_t>(s_shift) | reinterpret_cast<uintptr_t>(s_mean) |
                          reinterpret_cast<uintptr_t>(s_rstd) | reinterpret_cast<uintptr_t>(dpool) |
@@ -1661,6 +1821,11 @@ extern "C" int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, con
     a.s_dpool = dpool; a.s_dsc1 = dsc1; a.s_U = U; a.s_inv_perm = inv_perm; a.s_s2sum = s2sum;
     a.s_partial = s_partial; a.ldsz = ldsz; a.ld_dpool = ld_dpool; a.ld_U = ld_U; a.s_avg = graph_avg;
     a.n_batch = B;
+    if (sliced32) {
+        a.nslices = F / 32;
+        a.ids_in_lds = nnz_max > 0 ? nnz_max : 0;
+        return launch_agg<8>(a, B, n_max, reinterpret_cast<hipStream_t>(stream));
+    }
     return launch_agg16(a, B, n_max, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1674,9 +1839,11 @@ extern "C" int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, co
                                   int ldh, float* gf, int ldgf, int graph_avg, float* y, int ldy, int F,
                                   const float* eps, int average, int self_loop, void* stream) {
     if (B <= 0) return GNM_OK;
-    if (F != 64 || gnm_agg_slice_width(F, n_max) != 64 || !y || !z || !scale || !shift)
-        return GNM_ERR_UNSUPPORTED;
-    if ((size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 32 + (size_t)1024 * 16 > (size_t)kLdsBudget - 1024)
+    // two shapes, as gnm_agg_bwd_stats: one 64-wide slice, or 32-float slices of a multiple of 32 (gnm_agg_kernel<8, 1>)
+    const int fs = gnm_agg_slice_width(F, n_max);
+    const bool wide64 = F == 64 && fs == 64, sliced32 = fs == 32 && (F & 31) == 0;
+    if ((!wide64 && !sliced32) || !y || !z || !scale || !shift) return GNM_ERR_UNSUPPORTED;
+    if (wide64 && (size_t)(n_max + 1) * 256 + (size_t)(n_max + 2) * 4 + 32 + (size_t)1024 * 16 > (size_t)kLdsBudget - 1024)
         return GNM_ERR_UNSUPPORTED;
     if ((ldz & 3) || (hout && (ldh & 3)) || (ldy & 3) || (gf && (ldgf & 3))) return GNM_ERR_UNSUPPORTED;
     const uintptr_t al = reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(scale) |
@@ -1689,9 +1856,13 @@ extern "C" int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, co
     a.node_off = node_off; a.x = z; a.y = y; a.eps = eps;
     a.ldx = ldz; a.ldy = ldy; a.F = F; a.nslices = 1;
     a.average = average; a.self_loop = self_loop; a.backward = 0;
-    (void)nnz_max;
     a.p_scale = scale; a.p_shift = shift; a.p_hout = hout; a.p_gf = gf; a.p_ldh = ldh; a.p_ldgf = ldgf;
     a.p_gf_avg = graph_avg;
+    if (sliced32) {
+        a.nslices = F / 32;
+        a.ids_in_lds = nnz_max > 0 ? nnz_max : 0;
+        return launch_agg<8>(a, B, n_max, reinterpret_cast<hipStream_t>(stream));      // (declines when LDS has no room for the shares)
+    }
     return launch_agg16(a, B, n_max, reinterpret_cast<hipStream_t>(stream));
 }
 

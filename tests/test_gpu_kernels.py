@@ -133,11 +133,17 @@ def test_agg_forward_backward(sizes, density, F, symmetric, average, learn_eps):
         assert abs(out.item() - want) <= 1e-6 * scale        # fp64 accumulation: far below fp32 noise
 
 
-@pytest.mark.parametrize("sizes,density", [([40, 40, 40], 0.3), ([400, 400], 0.3), ([64] * 9, 0.5), ([3] * 50, 0.9),
-                                           ([9, 2, 12], 0.5)])
+# (sizes, density, F): the 64-wide single-slice shape (gnm_agg16_kernel), and 32-float slices (gnm_agg_kernel<8, MODE>:
+# hidden_dim 128 on graphs of 625-1231 nodes = configs[3]; 96 = three slices; 32 = one slice, small workgroups)
+FUSED_AGG_CASES = [([40, 40, 40], 0.3, 64), ([400, 400], 0.3, 64), ([64] * 9, 0.5, 64), ([3] * 50, 0.9, 64),
+                   ([9, 2, 12], 0.5, 64), ([700, 1000, 650], 0.02, 128), ([1100, 30, 1], 0.02, 96),
+                   ([40, 9, 64, 1, 333], 0.3, 32), ([1000] * 3, 0.09, 128)]
+
+
+@pytest.mark.parametrize("sizes,density,F", FUSED_AGG_CASES)
 @pytest.mark.parametrize("average,learn_eps,graph_avg,disc", [(0, 1, 0, True), (1, 1, 1, True), (0, 0, 0, False),
                                                               (1, 0, 1, True)])
-def test_agg_backward_fused_with_bn_stats(sizes, density, average, learn_eps, graph_avg, disc):
+def test_agg_backward_fused_with_bn_stats(sizes, density, F, average, learn_eps, graph_avg, disc):
     """gnm_agg_bwd_stats == gnm_agg(backward) followed by gnm_bn_relu_bwd_stats (readout, discriminator and
     quirk-row terms, ReLU mask, per-graph BatchNorm-backward sums), to fp32 rounding."""
     from gnm import core
@@ -148,7 +154,7 @@ def test_agg_backward_fused_with_bn_stats(sizes, density, average, learn_eps, gr
     ar = GraphArena(DEV)
     batch = ar.batch(graphs)
     batch.dense = False              # CSR kernels on both sides of the comparison
-    N, B, F = batch.N, batch.B, 64
+    N, B = batch.N, batch.B
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
     dp = t(rng.standard_normal((N, F)).astype(np.float32))
     hf = t(rng.standard_normal((N, F)).astype(np.float32))
@@ -220,7 +226,7 @@ def test_agg_backward_fused_with_bn_stats(sizes, density, average, learn_eps, gr
     assert lib.gnm_agg_bwd_stats(a.rowptr.buf.data_ptr(), a.col.buf.data_ptr(), batch.t_rp_off.data_ptr(),
                                  batch.t_col_off.data_ptr(), a.rowptr.buf.data_ptr(), batch.rp_off.data_ptr(),
                                  batch.node_off.data_ptr(), B, batch.n_max, batch.nnz_max, dp.data_ptr(), F,
-                                 G.data_ptr(), F, 32, epsp, average, int(not learn_eps), None, 0, None, Z.data_ptr(), F,
+                                 G.data_ptr(), F, 48, epsp, average, int(not learn_eps), None, 0, None, Z.data_ptr(), F,
                                  sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), rs.data_ptr(), None, 0, 0, None, None, 0,
                                  None, None, p_f.data_ptr(), _stream()) == -2
 
@@ -805,10 +811,11 @@ def test_discriminator_unit_declines_outside_its_forms():
     assert rc == -2
 
 
-@pytest.mark.parametrize("sizes,density", [([40, 40, 40], 0.3), ([37, 5, 64, 1, 23], 0.4), ([400, 400, 400], 0.3),
-                                           ([50, 50], 0.0)])
+@pytest.mark.parametrize("sizes,density,F", [([40, 40, 40], 0.3, 64), ([37, 5, 64, 1, 23], 0.4, 64), ([400, 400, 400], 0.3, 64),
+                                             ([50, 50], 0.0, 64), ([700, 1000, 650], 0.02, 128), ([1100, 30, 1], 0.02, 96),
+                                             ([40, 9, 64, 1, 333], 0.3, 32), ([1000] * 3, 0.09, 128)])
 @pytest.mark.parametrize("average,learn_eps,graph_avg", [(0, 1, 0), (1, 1, 1), (0, 0, 1), (1, 0, 0)])
-def test_agg_forward_with_fused_bn_relu_readout(sizes, density, average, learn_eps, graph_avg):
+def test_agg_forward_with_fused_bn_relu_readout(sizes, density, F, average, learn_eps, graph_avg):
     """gnm_agg_fwd_bnrelu (previous layer's BatchNorm + ReLU + readout on the aggregation's tile load) vs the fp64
     restatement of graphcnn.py:163-166, 229, 154-161 / 178-182."""
     from gnm._cabi import check, lib
@@ -818,7 +825,7 @@ def test_agg_forward_with_fused_bn_relu_readout(sizes, density, average, learn_e
     ar = GraphArena(DEV)
     batch = ar.batch(graphs)
     A = dense_adj(graphs)
-    N, F, B = batch.N, 64, batch.B
+    N, B = batch.N, batch.B
     z = rng.standard_normal((N, F)).astype(np.float32)
     sc = rng.uniform(0.5, 1.5, F).astype(np.float32)
     sh = (rng.standard_normal(F) * 0.3).astype(np.float32)
@@ -862,12 +869,25 @@ def test_agg_fused_bn_relu_refuses_other_shapes():
     rng = np.random.default_rng(0)
     ar = GraphArena(DEV)
     batch = ar.batch(random_graphs(rng, [30, 30], 0.3, True))
-    z = torch.zeros((60, 32), device=DEV)
-    v = torch.zeros(32, device=DEV)
+    z = torch.zeros((60, 48), device=DEV)            # (neither the 64-wide shape nor whole 32-float slices)
+    v = torch.zeros(48, device=DEV)
     assert lib.gnm_agg_fwd_bnrelu(ar.rowptr.buf.data_ptr(), ar.col.buf.data_ptr(), batch.rp_off.data_ptr(),
                                   batch.col_off.data_ptr(), batch.node_off.data_ptr(), 2, batch.n_max, batch.nnz_max,
-                                  z.data_ptr(), 32, v.data_ptr(), v.data_ptr(), z.data_ptr(), 32, None, 0, 0,
-                                  z.data_ptr(), 32, 32, None, 0, 1, _stream()) == -2
+                                  z.data_ptr(), 48, v.data_ptr(), v.data_ptr(), z.data_ptr(), 48, None, 0, 0,
+                                  z.data_ptr(), 48, 48, None, 0, 1, _stream()) == -2
+    # a 32-float slice that fills LDS to the last kilobyte (1231 nodes) leaves no room for the readout shares: declined
+    # before anything is launched (the caller then runs gnm_bn_relu_readout + gnm_agg)
+    ar2 = GraphArena(DEV)
+    b2 = ar2.batch(random_graphs(rng, [1231, 5], 0.01, True))
+    assert lib.gnm_agg_slice_width(128, b2.n_max) == 32
+    z2 = torch.zeros((b2.N, 128), device=DEV)
+    v2 = torch.zeros(128, device=DEV)
+    y2 = torch.full((b2.N, 128), float("nan"), device=DEV)
+    assert lib.gnm_agg_fwd_bnrelu(ar2.rowptr.buf.data_ptr(), ar2.col.buf.data_ptr(), b2.rp_off.data_ptr(),
+                                  b2.col_off.data_ptr(), b2.node_off.data_ptr(), 2, b2.n_max, b2.nnz_max,
+                                  z2.data_ptr(), 128, v2.data_ptr(), v2.data_ptr(), None, 0, None, 0, 0,
+                                  y2.data_ptr(), 128, 128, None, 0, 1, _stream()) == -2
+    assert torch.isnan(y2).all()
 
 
 @pytest.mark.parametrize("N,F,pad", [(1200, 7, 0), (1203, 7, 0), (37, 64, 0), (500, 7, 5), (1, 3, 0)])
