@@ -319,7 +319,9 @@ extern "C" int gnm_disc_score_fwd_unit(const float* const* hptrs, const float* c
 __global__ void __launch_bounds__(256) gnm_disc_unit_scale_kernel(const float* __restrict__ unit, int ldunit, int LH,
                                                                   const float* __restrict__ k, float kscale,
                                                                   float* __restrict__ dU, int ldu,
-                                                                  float* __restrict__ s2sum, float* __restrict__ dsum) {
+                                                                  float* __restrict__ s2sum, float* __restrict__ dsum,
+                                                                  float* __restrict__ dbias, int B) {
+    __shared__ float red[256];
     const int g = blockIdx.x;
     const float kv = *k * kscale;                 // (one fp32 product, as the loss-gradient kernel forms its factor)
     const float* row = unit + (size_t)g * ldunit;
@@ -328,14 +330,27 @@ __global__ void __launch_bounds__(256) gnm_disc_unit_scale_kernel(const float* _
         s2sum[g] = kv * row[LH];
         if (dsum) dsum[g] = kv * row[LH + 1];
     }
+    // the Bilinear bias gradient = sum over the graphs of dsum (discriminator.py:19: one scalar): workgroup 0 adds the B
+    // values itself, in a fixed order (strided partials, then a tree) -- a torch.sum launch of the caller before
+    if (dbias && g == 0) {
+        float s = 0.f;
+        for (int q = threadIdx.x; q < B; q += 256) s += kv * unit[(size_t)q * ldunit + LH + 1];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) *dbias = red[0];
+    }
 }
 
 extern "C" int gnm_disc_unit_scale(const float* unit, int ldunit, int LH, const float* k, float kscale, int B, float* dU,
-                                   int ldu, float* s2sum, float* dsum, void* stream) {
+                                   int ldu, float* s2sum, float* dsum, float* dbias, void* stream) {
     if (B <= 0) return GNM_OK;
     if (!unit || !k || !dU || !s2sum || LH <= 0 || ldunit < LH + 2) return GNM_ERR_BAD_ARG;
     hipLaunchKernelGGL(gnm_disc_unit_scale_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), unit,
-                       ldunit, LH, k, kscale, dU, ldu, s2sum, dsum);
+                       ldunit, LH, k, kscale, dU, ldu, s2sum, dsum, dbias, B);
     GNM_CHECK_LAUNCH();
     return GNM_OK;
 }

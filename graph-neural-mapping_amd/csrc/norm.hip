@@ -180,6 +180,38 @@ extern "C" int gnm_bn_relu_readout(const float* Z, int ldz, const float* scale, 
 }
 
 // ---------------------------------------------------------------------------------
+// X_concat (graphcnn.py:195): the rows of every graph of the batch, copied from where the arena keeps them
+// (base[b] = first row of graph b in src) to their place in the batch (node_off[b]).  One workgroup per graph; a second
+// source / destination pair of the same shape rides along (the arena's cached layer-0 aggregate).  Stands in for the
+// arange + broadcast-add + two index_select launches torch needed for the same rows.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gnm_gather_graph_rows_kernel(
+    const float* __restrict__ src, const float* __restrict__ src2, int lds, int width, const long long* __restrict__ base,
+    const int32_t* __restrict__ node_off, float* __restrict__ dst, float* __restrict__ dst2, int ldd) {
+    const int b = blockIdx.x;
+    const int row0 = node_off[b];
+    const int n = node_off[b + 1] - row0;
+    const long long s0 = base[b];
+    const int total = n * width;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int r = i / width, c = i - r * width;
+        const size_t so = (size_t)(s0 + r) * lds + c, dof = (size_t)(row0 + r) * ldd + c;
+        dst[dof] = src[so];
+        if (src2) dst2[dof] = src2[so];
+    }
+}
+
+extern "C" int gnm_gather_graph_rows(const float* src, const float* src2, int lds, int width, const long long* base,
+                                     const int32_t* node_off, int B, float* dst, float* dst2, int ldd, void* stream) {
+    if (B <= 0) return GNM_OK;
+    if (!src || !dst || !base || !node_off || width <= 0 || lds < width || ldd < width || (src2 && !dst2)) return GNM_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gnm_gather_graph_rows_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, src2,
+                       lds, width, base, node_off, dst, dst2, ldd);
+    GNM_CHECK_LAUNCH();
+    return GNM_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // backward, pass 1: assemble the gradient arriving at a BatchNorm+ReLU output from
 // all of its producers, apply the ReLU mask, and reduce the two BatchNorm sums.
 //   total[v,c] = dH[v,c]                                   (next layer's aggregation backward)

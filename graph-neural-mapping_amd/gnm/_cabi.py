@@ -63,6 +63,7 @@ SIGNATURES = {
     "gnm_small_gemm": (_i, [_p, _i, _i, _p, _i, _i, _p, _i, _i, _i, _i, _p]),
     "gnm_reduce_partials_multi": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "gnm_bn_finalize": (_i, [_p, _i, _i, _ll, _p, _p, _p, _p, _p, _f, _f, _i, _i, _p, _p, _p, _p, _p]),
+    "gnm_gather_graph_rows": (_i, [_p, _p, _i, _i, _p, _p, _i, _p, _p, _i, _p]),
     "gnm_bn_relu_readout": (_i, [_p, _i, _p, _p, _p, _i, _p, _i, _i, _i, _p, _i, _i, _p]),
     "gnm_bn_relu_bwd_stats": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p,
                                    _i, _i, _p, _p]),
@@ -77,7 +78,7 @@ SIGNATURES = {
                              _p, _i, _p, _p, _i, _p]),
     "gnm_disc_score_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p]),
     "gnm_disc_score_fwd_unit": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _p, _p]),
-    "gnm_disc_unit_scale": (_i, [_p, _i, _i, _p, _f, _i, _p, _i, _p, _p, _p]),
+    "gnm_disc_unit_scale": (_i, [_p, _i, _i, _p, _f, _i, _p, _i, _p, _p, _p, _p]),
     "gnm_disc_score_bwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p, _p, _p]),
     "gnm_head_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     "gnm_head_bwd": (_i, [_p, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),

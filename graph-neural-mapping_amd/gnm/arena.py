@@ -376,9 +376,25 @@ class GraphArena:
         start = torch.repeat_interleave(torch.as_tensor(batch.node_off_host[:-1], device=self.device), ns)
         return base + (torch.arange(batch.N, device=self.device) - start)
 
+    def _gather_rows(self, batch, second=None):
+        """rows of the batch's graphs out of the feature buffer (and out of `second`, an array of the same shape):
+        one launch of gnm_gather_graph_rows (csrc/norm.hip) on a GPU arena; index_select on a host arena (tests)."""
+        if self.device.type != "cuda":
+            idx = self._feature_rows(batch)
+            return self.feat.buf.index_select(0, idx), (second.index_select(0, idx) if second is not None else None)
+        src = self.feat.buf
+        W = src.shape[1]
+        X = torch.empty((batch.N, W), dtype=torch.float32, device=self.device)
+        Y = torch.empty_like(X) if second is not None else None
+        check(lib.gnm_gather_graph_rows(src.data_ptr(), second.data_ptr() if second is not None else None, src.stride(0),
+                                        W, batch.feat_base.data_ptr(), batch.node_off.data_ptr(), batch.B, X.data_ptr(),
+                                        Y.data_ptr() if Y is not None else None, X.stride(0),
+                                        torch.cuda.current_stream(self.device).cuda_stream), "gnm_gather_graph_rows")
+        return X, Y
+
     def features(self, batch):
         """X_concat (graphcnn.py:195) gathered on the device: [N, F0] fp32."""
-        return self.feat.buf.index_select(0, self._feature_rows(batch))
+        return self._gather_rows(batch)[0]
 
     # layer 0's neighbour aggregation of the INPUT features does not depend on any parameter:
     #   learn_eps:  pooled_0 = A X [/deg] + (1 + eps_0) X      (graphcnn.py:154-161)  -> cache A X [/deg]
@@ -443,11 +459,11 @@ class GraphArena:
     def features_and_agg0(self, batch, average, self_loop):
         """(X_concat, cached layer-0 aggregate) for the batch; the second is None when the cache would
         exceed AGG0_CACHE_BYTES (wide one-hot inputs on huge pools)."""
-        idx = self._feature_rows(batch)
-        X = self.feat.buf.index_select(0, idx)
         if self.feat.buf.numel() * 4 > self.AGG0_CACHE_BYTES:
-            return X, None
-        return X, self._agg0_store(average, self_loop).index_select(0, idx)
+            return self._gather_rows(batch)[0], None
+        store = self._agg0_store(average, self_loop)
+        assert store.shape == self.feat.buf.shape and store.stride(0) == self.feat.buf.stride(0)
+        return self._gather_rows(batch, store)
 
     # ------------------------------------------------------------------ parity export
     def export_adj_coo(self, batch, self_loops):

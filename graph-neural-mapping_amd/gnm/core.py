@@ -802,15 +802,19 @@ class GinInfoMaxFn(torch.autograd.Function):
             dU = torch.empty_like(U)
             s2sum = torch.empty(B, **f32)
             dsum = torch.empty(B, **f32)
+            dbias = None
             hold = ctx.disc_unit
             if (hold is not None and hold.k is not None and hold.dD_ptr == dD.data_ptr()
                     and hold.dD_version == dD._version):      # (same tensor AND untouched since the loss wrote it)
                 # dD = k (sigmoid(d_logit) - target) came straight from the loss that recorded k: the reductions are k
                 # times what the forward left (DiscUnit) -- no second pass over the hidden layers
                 inv_perm = hold.inv_perm
+                # (the Bilinear bias gradient -- the total of dsum -- comes out of the same launch)
+                dbias = sink["disc.f_k.bias"] if sink is not None else torch.empty(1, **f32)
                 check(lib.gnm_disc_unit_scale(hold.unit.data_ptr(), hold.unit.stride(0), L * H, hold.k.data_ptr(),
                                               float(getattr(hold, "kscale", 1.0)), B,
-                                              dU.data_ptr(), dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(), st),
+                                              dU.data_ptr(), dU.stride(0), s2sum.data_ptr(), dsum.data_ptr(),
+                                              dbias.data_ptr(), st),
                       "gnm_disc_unit_scale")
             else:
                 inv_perm = torch.empty(B, dtype=torch.int32, device=dev)      # inverse permutation, on the device
@@ -831,10 +835,11 @@ class GinInfoMaxFn(torch.autograd.Function):
             if not _small_gemm(dU, 1, c, 1, dWd, dU.shape[1], c.shape[1], Bc):          # dWd = dU^T c
                 torch.mm(dU.t(), c, out=dWd)
             if sink is not None:
-                torch.sum(dsum, 0, keepdim=True, out=sink["disc.f_k.bias"])
+                if dbias is None:
+                    torch.sum(dsum, 0, keepdim=True, out=sink["disc.f_k.bias"])
             else:
                 grads["disc.f_k.weight"] = dWd.unsqueeze(0)
-                grads["disc.f_k.bias"] = dsum.sum().reshape(1)
+                grads["disc.f_k.bias"] = dbias if dbias is not None else dsum.sum().reshape(1)
             T = torch.empty((Bc, Wd.shape[1]), **f32)
             if not _small_gemm(dU, 0, Wd, 1, T, Bc, Wd.shape[1], Wd.shape[0]):            # d loss / d sigmoid(g_f) = dU Wd
                 T = dU @ Wd

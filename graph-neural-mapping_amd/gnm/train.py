@@ -29,6 +29,9 @@ class _InfomaxLossFn(torch.autograd.Function):
     def forward(ctx, c_logit, d_logit, labels, d_target, beta, n_pos, hold=None):
         if not c_logit.is_cuda:
             raise RuntimeError("infomax_loss runs on the GPU only (libgnm_hip.so)")
+        # (`parts` is not differentiable: without this autograd hands backward() a freshly zero-filled gradient for it --
+        #  a fill launch per step)
+        ctx.set_materialize_grads(False)
         c = c_logit.contiguous()
         d = d_logit.contiguous().view(-1)
         B, C_ = c.shape
@@ -58,6 +61,8 @@ class _InfomaxLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gparts):
         c, d, lab, tgt, n_pos, beta, dshape = ctx.args
+        if g is None:                  # only `parts` was used downstream: nothing flows back
+            return (None,) * 7
         B, C_ = c.shape
         M = d.numel()
         g = g.to(torch.float32).contiguous()

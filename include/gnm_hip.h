@@ -252,6 +252,11 @@ int gnm_bn_finalize(const double* stats_partial, int nblk, int H, long long nrow
 int gnm_bn_relu_readout(const float* Z, int ldz, const float* scale, const float* shift, float* Hout, int ldh,
                         const int32_t* node_off, int B, int H, int relu, float* pooled, int ldp, int average,
                         void* stream);
+/* X_concat (/root/reference models/graphcnn.py:195): dst[node_off[b] + r, :width] = src[base[b] + r, :width] for the n_b
+ * rows of every graph b of the batch (base: int64 [B], first row of the graph where the arena keeps its features);
+ * src2 / dst2 (may be null): a second array of the same shape copied alongside. */
+int gnm_gather_graph_rows(const float* src, const float* src2, int lds, int width, const long long* base,
+                          const int32_t* node_off, int B, float* dst, float* dst2, int ldd, void* stream);
 /* Backward pass 1: G = (dH + readout grad + discriminator grads) * relu mask, and the
  * per-graph (sum G, sum G*xhat) partials [B][2][H]. */
 int gnm_bn_relu_bwd_stats(const float* dH, int lddh, const float* dpool, int ldp, int average, const float* dsc1,
@@ -326,9 +331,11 @@ int gnm_disc_score_fwd_unit(const float* const* hptrs_host, const float* const* 
                             const float* const* shift_ptrs_host, int ldh, int L, int H, const float* U, int ldu,
                             const int32_t* perm_rows, const float* bias, const int32_t* node_off, int N, int B,
                             float* d_logit, float* unit, int ldunit, int32_t* inv_perm, void* stream);
-/* dU = k * unit[:, :LH], s2sum = k * unit[:, LH], dsum = k * unit[:, LH + 1] (dsum may be NULL); k: DEVICE scalar. */
+/* dU = k * unit[:, :LH], s2sum = k * unit[:, LH], dsum = k * unit[:, LH + 1] (dsum may be NULL); k: DEVICE scalar
+ * (times the host factor kscale).  dbias (may be NULL): one float, the sum of dsum over the B graphs = the gradient of
+ * the Bilinear's bias (/root/reference models/discriminator.py:19), added in a fixed order by the same launch. */
 int gnm_disc_unit_scale(const float* unit, int ldunit, int LH, const float* k, float kscale, int B, float* dU, int ldu,
-                        float* s2sum, float* dsum, void* stream);
+                        float* s2sum, float* dsum, float* dbias, void* stream);
 /* optional by-products: dsum[g] = sum over graph g of dD (both halves; their total is d bias), and
  * inv_perm[perm_rows[g]] = g. */
 int gnm_disc_score_bwd(const float* const* hptrs_host, const float* const* scale_ptrs_host,

@@ -771,8 +771,11 @@ def test_discriminator_unit_reductions_equal_the_backward_pass(B, n, L, H, as_z)
     dD64 = float(k) * (1.0 / (1.0 + np.exp(-x64)) - tgt)
     kd = t(np.array([k], dtype=np.float32))
     dU, s2, dsum = torch.empty((B, LH), device=DEV), torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    dbias = torch.full((1,), float("nan"), device=DEV)
     check(lib.gnm_disc_unit_scale(unit.data_ptr(), ldunit, LH, kd.data_ptr(), 1.0, B, dU.data_ptr(), LH, s2.data_ptr(),
-                                  dsum.data_ptr(), _stream()), "unit scale")
+                                  dsum.data_ptr(), dbias.data_ptr(), _stream()), "unit scale")
+    # the Bilinear bias gradient of the same launch = the total of dsum (discriminator.py:19)
+    assert abs(float(dbias.item()) - float(dD64.sum())) <= 1e-5 * float(np.abs(dD64).sum())
     # (a) against the fp64 statement of the reductions
     d1, d2 = dD64[:N], dD64[N:]
     s2_ref = d2.reshape(B, n).sum(1)
