@@ -648,9 +648,10 @@ def main():
                         ", with fused BatchNorm+ReLU+readout prologue" if fused else "")
                     variant = "fused_bnrelu" if fused else "plain"
                 else:
-                    kname = "gnm_agg_kernel<%d> (forward, F=%d as %d slices of %d floats per graph)" % (
-                        fs // 4, H, (H + fs - 1) // fs, fs)
-                    variant = "sliced_n%d_F%d" % (n, H)
+                    kname = "gnm_agg_kernel<%d, %d> (forward%s, F=%d as %d slices of %d floats per graph)" % (
+                        fs // 4, 1 if fused else 0, " with fused BatchNorm+ReLU+readout prologue" if fused else "", H,
+                        (H + fs - 1) // fs, fs)
+                    variant = "sliced_%sn%d_F%d" % ("fused_" if fused else "", n, H)
                 traffic, traffic_src = None, "not measured for this configuration"
                 if default_cfg:
                     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_agg.sh), counted on a 1024-graph

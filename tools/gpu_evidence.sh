@@ -22,6 +22,8 @@ for m in mplain mfused mbwdstats; do
   echo "== pmc $m"; bash tools/pmc_agg.sh ${T}_$m $m 2>&1 | tail -5
 done
 bash tools/pmc_agg.sh ${T}_c4 plain "--knn --F 128 --batch 256 --pool 256" 2>&1 | tail -5
+bash tools/pmc_agg.sh ${T}_c4f fused "--knn --F 128 --batch 256 --pool 256" 2>&1 | tail -5
+bash tools/pmc_agg.sh ${T}_c4b bwdstats "--knn --F 128 --batch 256 --pool 256" 2>&1 | tail -5
 bash tools/pmc_lin.sh ${T} 2>&1 | tail -4
 bash tools/pmc_step.sh ${T} 2>&1 | tail -2
 cd /tmp && export TMPDIR=/tmp

@@ -5,7 +5,8 @@
     stamped with the sha256 of the csrc/agg.hip the counters were taken on.
 
 usage: python tools/pmc_agg_summary.py <gpurun_out/pmc_agg_TAG> <variant> <kernel-name-substring> <out.md> [graphs] [source]
-  variant: plain | fused_bnrelu | backward_stats | sliced_n1000_F128 | mfma_plain | mfma_fused_bnrelu | mfma_backward_stats
+  variant: plain | fused_bnrelu | backward_stats | sliced_n1000_F128 | sliced_fused_n1000_F128 | sliced_bwdstats_n1000_F128 |
+           mfma_plain | mfma_fused_bnrelu | mfma_backward_stats
   source:  the csrc file the kernel lives in (default agg.hip; aggm.hip for the mfma_* variants) -- its sha256 is
            recorded with the entry, and bench.py drops the entry once that file changes
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE in KB units (MI355X_MICROARCH.md, HBM section: on gfx950 FETCH_SIZE reports
