@@ -88,8 +88,10 @@ int gnm_agg(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off,
 /* gnm_agg(backward = 1) for the layer-output gradient, fused with what gnm_bn_relu_bwd_stats would then do
  * for the BatchNorm+ReLU that produced that layer output (graphcnn.py:163-166 of the layer below): y becomes
  * G = (A^T x [+ self terms] + w_b*dpool[b] + dsc1[v]*U[b] + quirk rows) * relu-mask(sZ), and s_partial receives
- * [B][2][64] doubles (sum G, sum G*xhat) for gnm_bn_bwd_finalize.  Only for F = 64 with the whole [n, 64] tile
- * in LDS; GNM_ERR_UNSUPPORTED otherwise (nothing is launched).  dpool / dsc1 (with U, inv_perm, s2sum) may be null.
+ * [B][2][F] doubles (sum G, sum G*xhat) for gnm_bn_bwd_finalize.  Two shapes: F = 64 with the whole [n, 64] tile
+ * in LDS, or an F that is whole 32-float slices where gnm_agg_slice_width(F, n_max) = 32 (hidden_dim 128 on graphs of
+ * 625-1231 nodes, round 4); GNM_ERR_UNSUPPORTED otherwise (nothing is launched).  dpool / dsc1 (with U, inv_perm,
+ * s2sum) may be null.
  * deps_partial with hfwd == NULL (learn_eps form only): the layer input h = relu(sZ*s_scale+s_shift) is recomputed in
  * the epilogue from the sZ row it already holds, so d eps costs no pass over h. */
 int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
@@ -104,8 +106,10 @@ int gnm_agg_bwd_stats(const int32_t* rowptr, const uint16_t* col, const int64_t*
  * relu(z*scale+shift) (hout may be NULL: the activation is then not written -- its other consumer, the
  * discriminator, can re-form it from z, see gnm_disc_score_fwd), gf[b,:] <- sum (mean when graph_avg) of h_l over
  * graph b (gf may be NULL), y <- the
- * aggregation of h_l.  64-wide single-slice shape only: GNM_ERR_UNSUPPORTED otherwise (then gnm_bn_relu_readout
- * followed by gnm_agg). */
+ * aggregation of h_l.  Two shapes: F = 64 as one 64-wide LDS slice, or an F that is whole 32-float slices where
+ * gnm_agg_slice_width(F, n_max) = 32 (hidden_dim 128 on graphs of 625-1231 nodes, round 4) with room in LDS for the
+ * readout shares; GNM_ERR_UNSUPPORTED otherwise, before anything is launched (then gnm_bn_relu_readout followed by
+ * gnm_agg). */
 int gnm_agg_fwd_bnrelu(const int32_t* rowptr, const uint16_t* col, const int64_t* b_rp_off, const int64_t* b_col_off,
                        const int32_t* node_off, int B, int n_max, int nnz_max, const float* z, int ldz,
                        const float* scale, const float* shift, float* hout, int ldh, float* gf, int ldgf,
