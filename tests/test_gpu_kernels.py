@@ -1270,3 +1270,40 @@ def test_narrow_linear_backward_recomputing_its_output(N, K, want_dx):
             assert_close(dA, dZ @ W.astype(np.float64), rtol=TOL, what=name + " dX")
         assert_close(dW, dZ.T @ X64, rtol=TOL, what=name + " dW")
         assert_close(db, dZ.sum(0), rtol=TOL, what=name + " db")
+
+
+@pytest.mark.parametrize("sizes,width,pad", [([5, 1, 12, 400], 7, 0), ([3] * 40, 7, 1), ([1000, 17], 128, 0), ([9], 3, 5)])
+@pytest.mark.parametrize("second", [False, True])
+def test_gather_graph_rows(sizes, width, pad, second):
+    """gnm_gather_graph_rows (X_concat, graphcnn.py:195): every graph's rows copied from its block of the store to its
+    place in the batch, a second array alongside; nothing else of the destination is touched."""
+    from gnm._cabi import check, lib
+    rng = np.random.default_rng(len(sizes) + width)
+    B, N = len(sizes), int(sum(sizes))
+    lds, ldd = width + pad, width + 2 * pad
+    # the store keeps the graphs in another order, with gaps between their blocks
+    order = rng.permutation(B)
+    base = np.zeros(B, dtype=np.int64)
+    at = 3
+    for g in order:
+        base[g] = at
+        at += sizes[g] + int(rng.integers(0, 4))
+    store = rng.standard_normal((at + 2, lds)).astype(np.float32)
+    store2 = rng.standard_normal((at + 2, lds)).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    sd, s2d, based = t(store), t(store2), t(base)
+    node_off = t(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32))
+    dst = torch.full((N, ldd), float("nan"), device=DEV)
+    dst2 = torch.full((N, ldd), float("nan"), device=DEV)
+    check(lib.gnm_gather_graph_rows(sd.data_ptr(), s2d.data_ptr() if second else None, lds, width, based.data_ptr(),
+                                    node_off.data_ptr(), B, dst.data_ptr(), dst2.data_ptr() if second else None, ldd,
+                                    _stream()), "gnm_gather_graph_rows")
+    rows = np.concatenate([np.arange(base[g], base[g] + sizes[g]) for g in range(B)])
+    assert np.array_equal(dst[:, :width].cpu().numpy(), store[rows][:, :width])
+    assert torch.isnan(dst[:, width:]).all()
+    if second:
+        assert np.array_equal(dst2[:, :width].cpu().numpy(), store2[rows][:, :width])
+    else:
+        assert torch.isnan(dst2).all()
+    assert lib.gnm_gather_graph_rows(sd.data_ptr(), s2d.data_ptr(), lds, width, based.data_ptr(), node_off.data_ptr(), B,
+                                     dst.data_ptr(), None, ldd, _stream()) == -1          # a second source needs its destination
