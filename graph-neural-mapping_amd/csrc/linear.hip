@@ -967,15 +967,22 @@ static int launch_lin_split(const LinArgs& a0, int grid, hipStream_t s) {
 // The fp32-instruction kernels run this shape at 121 us per [256,000 x 128 x 128] launch = 69 TFLOP/s, 44 % of the
 // fp32 matrix peak, while moving 2.1 TB/s: matrix-pipe bound.  The K = 64 kernel above does not stretch -- three weight
 // planes of [128 x 128] are 98 KB and its per-wave fp32 staging image would be 17 KB: room for 3 waves -- so this one
-// keeps ONLY the weight planes in LDS and loads the A fragments in operand order straight from global memory: lane
-// (i, h) reads row i's 32 bytes at k = 64 kk + 8 m + 32 h (two 16-byte loads per m; a row's 512 bytes are touched by
-// 16 instructions of the same wave, served by L1 / L2 after the first), splits them in registers (optionally after the
-// BatchNorm + ReLU prologue, whose vectors sit in LDS) and issues the six bf16 terms per 16 k against the planes.
+// keeps the weight planes in LDS and stages the input ONE 16-k SLICE of a tile at a time through a 2.5 KB per-wave
+// image: four lanes read a row's 64 contiguous bytes of the slice (16 rows per instruction, whole 64-byte sectors), the
+// image is read back in operand order (lane (i, h): row i, k = 16 step + 8 h + 0..7), split in registers (optionally
+// after the BatchNorm + ReLU prologue, whose vectors sit in LDS) and multiplied as six bf16 terms against the planes.
+// (Round 3 loaded the operands straight from global memory, every lane its own row: 64 requests of 16 useful bytes per
+//  instruction, each 128-byte line touched by eight instructions -- the launch ran at 6.8 B/clk per CU where the K = 64
+//  kernel, whose loads are row-contiguous, gets 9.5: round 4.)  The next slice -- across tile boundaries too, under the
+// epilogue's stores -- is requested before the current one is multiplied.
 // Twelve waves per CU (one workgroup; 168 registers), tiles of 32 rows dealt to the waves as in the K = 64 kernel, so
 // the launch writes the same gnm_linear_grid(N) rows of statistics partials.  The accumulators are stored as they stand
 // (lane = column: 128-byte row segments, 4 bytes per lane).
 // ---------------------------------------------------------------------------------
 static constexpr int kSplit128Waves = 12;
+#ifndef GNM_L128_ABLATE          // tuning builds (tools/build_variant.py -DGNM_L128_ABLATE=n): 1 = no output stores,
+#define GNM_L128_ABLATE 0        // 2 = slices come from an empty descriptor (no input traffic)
+#endif
 
 template <bool MASKED>
 __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(const LinArgs p) {
@@ -987,16 +994,21 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
     // column statistics of this wave, fp64, in LDS ([2][HP] per wave: 16 registers a lane could not spare -- with them
     // in registers the tile loop spilled 21)
     double* wst = reinterpret_cast<double*>(smem + (size_t)3 * E * 16 + 3 * K * 4) + (size_t)(threadIdx.x >> 6) * 2 * HP;
+    // the wave's slice image: [32 rows][16 k + 4 floats of padding] (80-byte rows: the 32-byte operand reads of 16
+    // consecutive rows fall on 64 distinct banks)
+    constexpr int XS = 20;
+    float* xs = reinterpret_cast<float*>(smem + (size_t)3 * E * 16 + 3 * K * 4 + (size_t)NW * 2 * HP * 8) +
+                (size_t)(threadIdx.x >> 6) * 32 * XS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31;
     const int h = lane >> 5;
     const bool pro = p.pro_scale != nullptr;
-    // weight planes: entry (kk, m, c, lane = 32 kg + n) = W[h = 32 c + n][k = 64 kk + 8 m + 32 kg + 0..7]
+    // weight planes: entry (step, c, lane = 32 kg + n) = W[h = 32 c + n][k = 16 step + 8 kg + 0..7]
     for (int e = tid; e < E; e += NT) {
-        const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) & 3, m = (e >> 8) & 3, kk = e >> 10;
-        const int k0 = 64 * kk + 8 * m + 32 * kg, hh = 32 * c + n;
+        const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) & 3, step = e >> 8;
+        const int k0 = 16 * step + 8 * kg, hh = 32 * c + n;
         float f[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -1016,35 +1028,65 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
     const int gw = lin_first_tile(wave, NW / 4, p.stat_rows);
     const int ntiles = (p.N + 31) / 32;
     const int tstride = 4 * p.stat_rows;
-    const int in_voff = (i * p.ldx + 32 * h) * 4;
+    // a slice request: lane -> row (lane >> 2) (+ 16 for the second instruction), 16-byte chunk (lane & 3) of the 64 bytes
+    const int ld_voff = ((lane >> 2) * p.ldx + 4 * (lane & 3)) * 4, ld_row16 = 16 * p.ldx * 4;
+    float* const xs_w = xs + (lane >> 2) * XS + 4 * (lane & 3);
+    const float* const xs_r = xs + i * XS + 8 * h;
     for (int e = lane; e < 2 * HP; e += 64) wst[e] = 0.0;       // (wave-private: no barrier needed)
 
-    for (int t = gw; t < ntiles; t += tstride) {
+    auto tile_rsrc_of = [&](int t) {          // (a tile past the end: an empty descriptor, every load returns zeros)
+        const int r0 = min(t, ntiles - 1) * 32;
+        return gnm_tile_rsrc(p.X + (size_t)r0 * p.ldx, (t < ntiles && !(GNM_L128_ABLATE & 2)) ? min(p.N - r0, 32) : 0, p.ldx, K);
+    };
+    // Slices are requested D steps ahead into a register ring (slot = slice index mod D): with one slice of 2 KB in
+    // flight per wave a CU had 24 KB on its way -- 12 GB/s per CU at the ~2 us a loaded HBM round trip takes, the 3.7 TB/s
+    // this kernel ran at; D = 4 (the plain form; the masked form has registers for 2) keeps up to 96 KB in flight.
+    constexpr int D = MASKED ? 2 : 4;
+    int t = gw;
+    u32x4 ring0[D], ring1[D];
+#pragma unroll
+    for (int q = 0; q < D; ++q) { ring0[q] = u32x4{0u, 0u, 0u, 0u}; ring1[q] = ring0[q]; }
+    if (t < ntiles) {
+        const __amdgpu_buffer_rsrc_t rs0 = tile_rsrc_of(t);
+#pragma unroll
+        for (int q = 0; q < D; ++q) {
+            ring0[q] = __builtin_amdgcn_raw_buffer_load_b128(rs0, ld_voff, q * 64, 0);
+            ring1[q] = __builtin_amdgcn_raw_buffer_load_b128(rs0, ld_voff + ld_row16, q * 64, 0);
+        }
+    }
+    // (the first tile is peeled below: the loop is then entered with the queue its back edge carries -- two slice loads
+    //  followed by the epilogue's stores -- and the wait for the slice is a counted one instead of a drain of the stores)
+    auto do_tile = [&](const int t) {
         const int r0 = t * 32;
         const int rows = min(p.N - r0, 32);
-        const __amdgpu_buffer_rsrc_t rs = gnm_tile_rsrc(p.X + (size_t)r0 * p.ldx, rows, p.ldx, K);
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc_of(t);
+        const __amdgpu_buffer_rsrc_t rs_next = tile_rsrc_of(t + tstride);
         f32x16 acc[HT];
 #pragma unroll
         for (int c = 0; c < HT; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-        // eight k steps of 16 (k = 64 kk + 8 m + 32 h + 0..7, step = 4 kk + m) as a REAL loop with the next step's two
-        // 16-byte loads requested before the current step's split and MFMAs (fully unrolled, the scheduler hoisted every
-        // load and split of the 192-MFMA body: 295 spilled registers; with all of a k half in flight still 40)
-        u32x4 cur0 = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, 0, 0);
-        u32x4 cur1 = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, 16, 0);
-#pragma nounroll
+        // slice 0 (requested under the previous tile's epilogue) into the image; LDS operations of one wave execute in
+        // order, so the image needs no second buffer and no barrier
+        *reinterpret_cast<u32x4*>(xs_w) = ring0[0];
+        *reinterpret_cast<u32x4*>(xs_w + 16 * XS) = ring1[0];
+        // eight k steps of 16, unrolled (the ring slots are compile-time) with a scheduling fence per step: left alone,
+        // the scheduler hoists every load and split of the 192-MFMA body (295 spilled registers in round 3)
+#pragma unroll
         for (int step = 0; step < 8; ++step) {
-            const int nstep = min(step + 1, 7);
-            const int nko = (64 * (nstep >> 2) + 8 * (nstep & 3)) * 4;
-            const u32x4 nxt0 = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, nko, 0);
-            const u32x4 nxt1 = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, nko + 16, 0);
-            const float4 v0 = __builtin_bit_cast(float4, cur0), v1 = __builtin_bit_cast(float4, cur1);
+            __builtin_amdgcn_sched_barrier(0);
+            {   // slice step + D -- of the next tile past the end of this one -- into the slot slice `step` has left
+                const int sl = step + D;
+                const __amdgpu_buffer_rsrc_t rq = sl < 8 ? rs : rs_next;
+                ring0[step % D] = __builtin_amdgcn_raw_buffer_load_b128(rq, ld_voff, (sl & 7) * 64, 0);
+                ring1[step % D] = __builtin_amdgcn_raw_buffer_load_b128(rq, ld_voff + ld_row16, (sl & 7) * 64, 0);
+            }
+            const float4 v0 = *reinterpret_cast<const float4*>(xs_r), v1 = *reinterpret_cast<const float4*>(xs_r + 4);
             float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             if (pro) {
                 // (a clipped row read zeros and the affine map moves them: its products land in accumulator rows that
                 //  are neither stored nor counted)
-                const int k0 = 64 * (step >> 2) + 8 * (step & 3) + 32 * h;
+                const int k0 = 16 * step + 8 * h;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const float4 sc = *reinterpret_cast<const float4*>(psv + k0 + 4 * q);
@@ -1073,10 +1115,14 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[c], 0, 0, 0);
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[c], 0, 0, 0);
             }
-            cur0 = nxt0; cur1 = nxt1;
+            if (step < 7) {       // the next slice into the image (behind this step's reads, in order)
+                *reinterpret_cast<u32x4*>(xs_w) = ring0[(step + 1) % D];
+                *reinterpret_cast<u32x4*>(xs_w + 16 * XS) = ring1[(step + 1) % D];
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- epilogue: bias, column statistics, stores (lane = column; rows past N clipped by the descriptor) ----
-        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, rows, p.ldz, HP);
+        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, (GNM_L128_ABLATE & 1) ? 0 : rows, p.ldz, HP);
         if constexpr (MASKED) {
             // masked dX: the values under the accumulators of the lower BatchNorm's input (lane = column: 128-byte row
             // pieces), one column block requested ahead of the one being finished
@@ -1120,6 +1166,9 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
                 }
             }
         } else {
+        // (one vector offset per lane, the (row, column block) part in the scalar offset: a vector offset per store is 64
+        //  registers the compiler keeps -- and spills -- across the tile loop)
+        const unsigned zvo = (unsigned)((4 * h * p.ldz + i) * 4);
 #pragma unroll
         for (int c = 0; c < HT; ++c) {
             float s1 = 0.f, s2 = 0.f;
@@ -1128,7 +1177,7 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
             for (int r = 0; r < 16; ++r) {
                 const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float z = acc[c][r] + bz;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), rz, (unsigned)((lrow * p.ldz + 32 * c + i) * 4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z), rz, zvo, (((r & 3) + 8 * (r >> 2)) * p.ldz + 32 * c) * 4, 0);
                 if (lrow < rows) {
                     s1 += z;
                     s2 += z * z;
@@ -1142,6 +1191,10 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
             }
         }
         }
+    };
+    if (t < ntiles) {
+        do_tile(t);
+        for (t += tstride; t < ntiles; t += tstride) do_tile(t);
     }
 
     if (p.stats_partial) {
@@ -1163,7 +1216,8 @@ static int launch_lin_split128(const LinArgs& a0, int grid, hipStream_t s) {
     LinArgs a = a0;
     a.stat_rows = grid;
     const int grid3 = (grid + 2) / 3;
-    const size_t lds = (size_t)3 * (2 * 4 * 4 * 64) * 16 + (size_t)3 * 128 * 4 + (size_t)kSplit128Waves * 2 * 128 * 8;
+    const size_t lds = (size_t)3 * (2 * 4 * 4 * 64) * 16 + (size_t)3 * 128 * 4 + (size_t)kSplit128Waves * 2 * 128 * 8 +
+                       (size_t)kSplit128Waves * 32 * 20 * 4;          // planes, prologue vectors, statistics, slice images
     if (a.mZ) {
         GNM_ALLOW_FULL_LDS((&gnm_lin_split128_kernel<true>));
         hipLaunchKernelGGL(gnm_lin_split128_kernel<true>, dim3(grid3), dim3(kSplit128Waves * 64), lds, s, a);

@@ -305,13 +305,15 @@ def test_split_precision_products_k128_are_fp32_accurate(wide):
         X64 = (np.maximum(X * sc + sh, 0) if pro else X).astype(np.float64)
         err = np.abs(Z.cpu().numpy() - (X64 @ W64.T + b)) / (np.abs(X64) @ np.abs(W64).T + np.abs(b))
         print("K = 128 split-precision forward (prologue %s): max error %.2e of sum |x||w|" % (pro is not None, err.max()))
-        assert err.max() < 1e-6
+        # (fp32 accumulation of 128 exact products: its own worst case is 128 x 2^-24 = 7.6e-6; the wide-range case
+        #  measures 0.9-1.1e-6 depending on the order the k steps are taken in)
+        assert err.max() < 1.5e-6
     dX = torch.empty(N, K, device=DEV)
     core._linear(Xd, Wd, 1, None, dX, N, H, K, None, None)
     X64 = X.astype(np.float64)
     e2 = np.abs(dX.cpu().numpy() - X64 @ W64) / (np.abs(X64) @ np.abs(W64))
     print("K = 128 split-precision k-major form: max error %.2e" % e2.max())
-    assert e2.max() < 1e-6
+    assert e2.max() < 1.5e-6
     # dW = dZ^T relu(sc X + sh) (gnm_wgrad_split128_kernel: batch row as the contraction index, 8,237 rows accumulated
     # in fp32 per workgroup and the workgroups' partials in a fixed order)
     from gnm._cabi import check, lib
