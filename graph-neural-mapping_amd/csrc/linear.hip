@@ -741,6 +741,9 @@ __device__ __forceinline__ void lin_split8(const float* f, u32x4& p1, u32x4& p2,
 }
 
 static constexpr int kSplitWaves = 12;
+#ifndef GNM_L64_ABLATE           // tuning builds (-DGNM_L64_ABLATE=n): 1 = no output stores, 2 = no input traffic
+#define GNM_L64_ABLATE 0
+#endif
 
 template <int HT>
 __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const LinArgs p) {
@@ -789,7 +792,7 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
     u32x4 raw[NLD];
     auto load_tile = [&](int tile) {
         const long long row0 = (long long)tile * 32;
-        const __amdgpu_buffer_rsrc_t rs = gnm_tile_rsrc(p.X + row0 * p.ldx, min((long long)p.N - row0, 32LL), p.ldx, KC);
+        const __amdgpu_buffer_rsrc_t rs = gnm_tile_rsrc(p.X + row0 * p.ldx, (GNM_L64_ABLATE & 2) ? 0LL : min((long long)p.N - row0, 32LL), p.ldx, KC);
 #pragma unroll
         for (int j = 0; j < NLD; ++j) raw[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, in_voff, j * in_step, 0);
     };
@@ -904,7 +907,7 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, min(p.N - r0, 32), p.ldz, HP);
+        const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, (GNM_L64_ABLATE & 1) ? 0 : min(p.N - r0, 32), p.ldz, HP);
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
             const int idx = lane + 64 * st;
