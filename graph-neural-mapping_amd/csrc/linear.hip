@@ -740,7 +740,10 @@ __device__ __forceinline__ void lin_split8(const float* f, u32x4& p1, u32x4& p2,
     }
 }
 
-static constexpr int kSplitWaves = 12;
+#ifndef GNM_SPLIT_WAVES           // tuning builds: 16 = four waves per SIMD (needs GNM_LIN_GRID=1024 to fill 256 CUs)
+#define GNM_SPLIT_WAVES 12
+#endif
+static constexpr int kSplitWaves = GNM_SPLIT_WAVES;
 #ifndef GNM_L64_ABLATE           // tuning builds (-DGNM_L64_ABLATE=n): 1 = no output stores, 2 = no input traffic
 #define GNM_L64_ABLATE 0
 #endif
@@ -859,7 +862,11 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // row i, k = 32 h + 0..31 -> four A fragments (m: k = 8 m + 32 h + 0..7) x three planes
+        load_tile(t + tstride);                   // past the last tile: an empty descriptor, no memory traffic
+        // row i, k = 32 h + 0..31 -> four A fragments (m: k = 8 m + 32 h + 0..7) x three planes, each split right in
+        // front of its MFMAs (GNM_L64_SPLIT_AHEAD: all four first, as until round 4 -- 36 more registers, and the
+        // splits cannot run in the MFMAs' shadow)
+#ifdef GNM_L64_SPLIT_AHEAD
         u32x4 A1[4], A2[4], A3[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -868,11 +875,23 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
             const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             lin_split8(f, A1[m], A2[m], A3[m]);
         }
-        load_tile(t + tstride);                   // past the last tile: an empty descriptor, no memory traffic
+#endif
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
+#ifdef GNM_L64_SPLIT_AHEAD
             const lin_bf16x8 a1 = __builtin_bit_cast(lin_bf16x8, A1[m]), a2 = __builtin_bit_cast(lin_bf16x8, A2[m]),
                              a3 = __builtin_bit_cast(lin_bf16x8, A3[m]);
+#else
+            u32x4 A1m, A2m, A3m;
+            {
+                const float4 v0 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m);
+                const float4 v1 = *reinterpret_cast<const float4*>(Xs + i * XS + KH * h + 8 * m + 4);
+                const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                lin_split8(f, A1m, A2m, A3m);
+            }
+            const lin_bf16x8 a1 = __builtin_bit_cast(lin_bf16x8, A1m), a2 = __builtin_bit_cast(lin_bf16x8, A2m),
+                             a3 = __builtin_bit_cast(lin_bf16x8, A3m);
+#endif
 #pragma unroll
             for (int c = 0; c < HT; ++c) {
                 const int e = (m * HT + c) * 64 + lane;
@@ -938,10 +957,10 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
         }
         __syncthreads();
         // three rows of partials per workgroup (waves 0-3, 4-7, 8-11): gnm_linear_grid(N) rows per launch, as always
-        for (int idx = tid; idx < 3 * 2 * HP; idx += NT) {
+        for (int idx = tid; idx < (NW / 4) * 2 * HP; idx += NT) {
             const int grp = idx / (2 * HP), rest = idx - grp * 2 * HP;
             const int which = rest / HP, col = rest - which * HP;
-            const int row = blockIdx.x * 3 + grp;
+            const int row = blockIdx.x * (NW / 4) + grp;
             if (row >= p.stat_rows) continue;
             double s = 0.0;
             for (int w = 4 * grp; w < 4 * grp + 4; ++w) s += red[(w * 2 + which) * HP + col];
@@ -954,7 +973,7 @@ template <int HT>
 static int launch_lin_split(const LinArgs& a0, int grid, hipStream_t s) {
     LinArgs a = a0;
     a.stat_rows = grid;
-    const int grid3 = (grid + 2) / 3;
+    const int grid3 = (grid + kSplitWaves / 4 - 1) / (kSplitWaves / 4);
     constexpr int HP = HT * 32;
     constexpr int XS = (64 > HP ? 64 : HP) + 4;
     const size_t lds = (size_t)3 * 4 * HT * 64 * 16 + (size_t)kSplitWaves * 32 * XS * 4;
