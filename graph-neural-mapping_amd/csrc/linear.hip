@@ -81,9 +81,13 @@ extern "C" void gnm_debug_set_lin_stamps(void* p) { g_lin_stamps = reinterpret_c
 #define GNM_RSTAMP(k)      /* gnm_linear_bwd_rz_kernel: eight waves per workgroup */                        \
     if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
         p.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime();
+#define GNM_SSTAMP(k)      /* gnm_lin_split_kernel: twelve waves per workgroup, six stamps per tile */        \
+    if (p.stamps && (threadIdx.x & 63) == 0)                                                                  \
+        p.stamps[((size_t)blockIdx.x * kSplitWaves + (threadIdx.x >> 6)) * 64 + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define GNM_LSTAMP(k)
 #define GNM_RSTAMP(k)
+#define GNM_SSTAMP(k)
 #endif
 
 template <int KC, int HT>
@@ -761,6 +765,7 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
     constexpr int NST = (32 * O4) / 64;
     constexpr int WSTEP = 64 / O4;
     constexpr int E = 4 * HT * 64;                // operand entries (16 B) per weight plane: [m][c][lane]
+    GNM_SSTAMP(0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* Wp = reinterpret_cast<u32x4*>(smem);                               // [3][E]
     float* Xs_all = reinterpret_cast<float*>(smem + (size_t)3 * E * 16);      // [NW][32][XS]; first the fp32 weight image
@@ -809,39 +814,46 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
         if (w_vec) return *reinterpret_cast<const float4*>(src);
         return make_float4(src[0], src[1], src[2], src[3]);
     };
-    if (p.w_kmajor) {
+    // entry (m, c, lane = 32 kg + n): W[k = 8 m + 32 kg + 0..7][h = 32 c + n] -- the k numbering the A fragments use
+    if (!p.w_kmajor) {
+        // torch's layout W[h][k]: an entry's eight k are 32 contiguous bytes of row h -- straight from global memory
+        // (L2) into the split; the fp32 image, its transposing scalar LDS writes and one of the two barriers were a
+        // fifth of a wave's lifetime (in-kernel timeline, tools/lin_timeline.py --kernel fwd_split)
+        for (int e = tid; e < E; e += NT) {
+            const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % HT, m = e / (64 * HT);
+            const float* src = p.W + (size_t)(32 * c + n) * p.ldw + 8 * m + 32 * kg;
+            const float4 w0 = load_w4(src), w1 = load_w4(src + 4);
+            const float f[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            u32x4 p1, p2, p3;
+            lin_split8(f, p1, p2, p3);
+            Wp[e] = p1; Wp[E + e] = p2; Wp[2 * E + e] = p3;
+        }
+    } else {
         for (int idx = tid; idx < KC * O4; idx += NT) {
             const int k = idx / O4, h4 = idx - k * O4;
             *reinterpret_cast<float4*>(Wt + k * HP + 4 * h4) = load_w4(p.W + (size_t)k * p.ldw + 4 * h4);
         }
-    } else {
-        for (int idx = tid; idx < C4 * HP; idx += NT) {
-            const int k4 = idx / HP, hh = idx - k4 * HP;
-            const float4 w = load_w4(p.W + (size_t)hh * p.ldw + 4 * k4);
-            Wt[(4 * k4 + 0) * HP + hh] = w.x;
-            Wt[(4 * k4 + 1) * HP + hh] = w.y;
-            Wt[(4 * k4 + 2) * HP + hh] = w.z;
-            Wt[(4 * k4 + 3) * HP + hh] = w.w;
-        }
-    }
-    __syncthreads();
-    // entry (m, c, lane = 32 kg + n): W[k = 8 m + 32 kg + 0..7][h = 32 c + n] -- the k numbering the A fragments use
-    for (int e = tid; e < E; e += NT) {
-        const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % HT, m = e / (64 * HT);
-        float f[8];
+        __syncthreads();
+        for (int e = tid; e < E; e += NT) {
+            const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) % HT, m = e / (64 * HT);
+            float f[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = Wt[(8 * m + 32 * kg + j) * HP + 32 * c + n];
-        u32x4 p1, p2, p3;
-        lin_split8(f, p1, p2, p3);
-        Wp[e] = p1; Wp[E + e] = p2; Wp[2 * E + e] = p3;
+            for (int j = 0; j < 8; ++j) f[j] = Wt[(8 * m + 32 * kg + j) * HP + 32 * c + n];
+            u32x4 p1, p2, p3;
+            lin_split8(f, p1, p2, p3);
+            Wp[e] = p1; Wp[E + e] = p2; Wp[2 * E + e] = p3;
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0): nothing from the preamble is pending inside the tile loop
     __syncthreads();
 
+    GNM_SSTAMP(1)
     double st1[HT], st2[HT];
 #pragma unroll
     for (int c = 0; c < HT; ++c) { st1[c] = 0.0; st2[c] = 0.0; }
+    int tk = 0;               // (tuning builds: tile counter of the timeline stamps)
     auto do_tile = [&](int t) {
+        GNM_SSTAMP(2 + 6 * min(tk, 9))
         const int r0 = t * 32;
         f32x16 acc[HT];
 #pragma unroll
@@ -862,6 +874,7 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GNM_SSTAMP(3 + 6 * min(tk, 9))
         load_tile(t + tstride);                   // past the last tile: an empty descriptor, no memory traffic
         // row i, k = 32 h + 0..31 -> four A fragments (m: k = 8 m + 32 h + 0..7) x three planes, each split right in
         // front of its MFMAs (GNM_L64_SPLIT_AHEAD: all four first, as until round 4 -- 36 more registers, and the
@@ -875,6 +888,7 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
             const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             lin_split8(f, A1[m], A2[m], A3[m]);
         }
+        GNM_SSTAMP(4 + 6 * min(tk, 9))
 #endif
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -905,19 +919,34 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
                 acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[c], 0, 0, 0);
             }
         }
+        GNM_SSTAMP(5 + 6 * min(tk, 9))
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();          // A fragments are in registers before the staging image is reused
+        // (only the launch's last tile can have rows past N: every other tile sums without the per-element row guard --
+        //  two selects per element, a fifth of the tile's vector instructions)
+        const bool full = r0 + 32 <= p.N;                  // wave-uniform
+        float* const xo = Xs + (4 * h) * XS + i;
 #pragma unroll
         for (int c = 0; c < HT; ++c) {
             float s1 = 0.f, s2 = 0.f;
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float z = acc[c][r] + bias_r[c];
-                Xs[lrow * XS + 32 * c + i] = z;
-                if (r0 + lrow < p.N) {
+                for (int r = 0; r < 16; ++r) {
+                    const float z = acc[c][r] + bias_r[c];
+                    xo[((r & 3) + 8 * (r >> 2)) * XS + 32 * c] = z;
                     s1 += z;
                     s2 += z * z;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lrow = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float z = acc[c][r] + bias_r[c];
+                    xo[((r & 3) + 8 * (r >> 2)) * XS + 32 * c] = z;
+                    if (r0 + lrow < p.N) {
+                        s1 += z;
+                        s2 += z * z;
+                    }
                 }
             }
             st1[c] += (double)s1;
@@ -926,22 +955,26 @@ __global__ void __launch_bounds__(kSplitWaves * 64) gnm_lin_split_kernel(const L
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        GNM_SSTAMP(6 + 6 * min(tk, 9))
         const __amdgpu_buffer_rsrc_t rz = gnm_tile_rsrc(p.Z + (size_t)r0 * p.ldz, (GNM_L64_ABLATE & 1) ? 0 : min(p.N - r0, 32), p.ldz, HP);
+        // (idx = lane + 64 st -> row = lane / O4 + WSTEP st, chunk = lane % O4: one address per lane, the rest immediates)
+        const float* const xi = Xs + (lane / O4) * XS + 4 * (lane % O4);
 #pragma unroll
         for (int st = 0; st < NST; ++st) {
-            const int idx = lane + 64 * st;
-            const int row = idx / O4, oc = idx - row * O4;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(Xs + row * XS + 4 * oc);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xi + st * WSTEP * XS);
             __builtin_amdgcn_raw_buffer_store_b128(v, rz, out_voff + st * out_step, 0, 0);     // (row step in the vector offset: see above)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        GNM_SSTAMP(7 + 6 * min(tk, 9))
+        ++tk;
     };
 
     if (t < ntiles) {
         do_tile(t);
         for (t += tstride; t < ntiles; t += tstride) do_tile(t);
     }
+    GNM_SSTAMP(62)
 
     if (p.stats_partial) {
         __syncthreads();
@@ -1032,9 +1065,16 @@ __global__ void __launch_bounds__(kSplit128Waves * 64) gnm_lin_split128_kernel(c
         const int n = e & 31, kg = (e >> 5) & 1, c = (e >> 6) & 3, step = e >> 8;
         const int k0 = 16 * step + 8 * kg, hh = 32 * c + n;
         float f[8];
+        if (!p.w_kmajor && (p.ldw & 3) == 0 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0) {     // (kernel-uniform)
+            // torch's layout: the entry's eight k are 32 contiguous bytes of row hh
+            const float4 w0 = *reinterpret_cast<const float4*>(p.W + (size_t)hh * p.ldw + k0);
+            const float4 w1 = *reinterpret_cast<const float4*>(p.W + (size_t)hh * p.ldw + k0 + 4);
+            f[0] = w0.x; f[1] = w0.y; f[2] = w0.z; f[3] = w0.w; f[4] = w1.x; f[5] = w1.y; f[6] = w1.z; f[7] = w1.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            f[j] = p.w_kmajor ? p.W[(size_t)(k0 + j) * p.ldw + hh] : p.W[(size_t)hh * p.ldw + k0 + j];
+            for (int j = 0; j < 8; ++j)
+                f[j] = p.w_kmajor ? p.W[(size_t)(k0 + j) * p.ldw + hh] : p.W[(size_t)hh * p.ldw + k0 + j];
+        }
         u32x4 p1, p2, p3;
         lin_split8(f, p1, p2, p3);
         Wp[e] = p1; Wp[E + e] = p2; Wp[2 * E + e] = p3;

@@ -10,7 +10,10 @@ fwd (gnm_lin_stream_kernel / gnm_lin_fast_kernel): 0 entry, 1 weight staged, per
   registers (X staged, A fragments read, next tile's loads issued), 4+4t MFMAs done, 5+4t tile stored; 62 loop left.
 bwd (gnm_linear_bwd_fused_kernel): 0 entry, 1 weight staged, per tile t: 2+5t start, 3+5t dZ tile staged (G and Z
   arrived) and X loads issued, 4+5t dgrad MFMAs done, 5+5t wgrad MFMAs done, 6+5t dX stored; 62 loop left, 63 exit
-  (dW / BatchNorm partials written)."""
+  (dW / BatchNorm partials written).
+fwd_split (gnm_lin_split_kernel, the K = H = 64 forward a step runs; build with -DGNM_LIN_TUNING -DGNM_L64_SPLIT_AHEAD so that
+  the splits sit in front of the MFMAs): per tile t: 2+6t start, 3+6t staged, 4+6t A planes split, 5+6t MFMAs done,
+  6+6t output image written, 7+6t stored; 62 loop left."""
 import argparse
 import ctypes as C
 import os
@@ -24,7 +27,7 @@ import torch
 from gnm import core
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--kernel", default="fwd", choices=["fwd", "bwd", "bwd_first", "rz", "rz_first"])
+ap.add_argument("--kernel", default="fwd", choices=["fwd", "fwd_split", "bwd", "bwd_first", "rz", "rz_first"])
 args = ap.parse_args()
 lib = core.lib
 lib.gnm_debug_set_lin_stamps.argtypes = [C.c_void_p]
@@ -41,7 +44,8 @@ mean, rstd, cA, m1, m2 = (torch.randn(H, **f32) * 0.1, torch.rand(H, **f32) + 0.
 lmean, lrstd = torch.randn(K, **f32) * 0.1, torch.rand(K, **f32) + 0.5
 dW, db = torch.empty(H, K, **f32), torch.empty(H, **f32)
 st = torch.cuda.current_stream().cuda_stream
-fwd = args.kernel == "fwd"
+fwd = args.kernel in ("fwd", "fwd_split")
+split = args.kernel == "fwd_split"       # gnm_lin_split_kernel (build with -DGNM_LIN_TUNING -DGNM_L64_SPLIT_AHEAD): 6 stamps per tile
 rz = args.kernel.startswith("rz")
 grid = lib.gnm_linear_grid(N) if fwd else lib.gnm_linear_bwd_grid(N)
 stats = torch.empty(grid, 2, H, dtype=torch.float64, device=dev)
@@ -85,13 +89,15 @@ e0.record(); run(); e1.record(); torch.cuda.synchronize()
 lib.gnm_debug_set_lin_stamps(None)
 ms = e0.elapsed_time(e1)
 s = stamps.cpu().numpy().reshape(nwg, WPB, 64).astype(np.float64)
-per = 4 if fwd else (6 if rz else 5)
-names = (["wait for X + stage + read A", "64 MFMAs (+ B from LDS)", "epilogue + stores"] if fwd else
+per = 6 if split else (4 if fwd else (6 if rz else 5))
+names = (["wait for X + prologue + stage (LDS writes, fence)", "next tile's loads + read A image + split (3 x 4 planes)",
+          "48 MFMAs (+ B planes from LDS)", "bias + statistics + output image (LDS writes, fence)", "read image + stores"] if split else
+         ["wait for X + stage + read A", "64 MFMAs (+ B from LDS)", "epilogue + stores"] if fwd else
          ["wait for X rows + split + Z MFMAs", "wait for G + dZ + image + issue X column loads", "dgrad (image rows, split, MFMAs)",
           "mask / statistics / staging + dX stores", "next tile's requests + wgrad (split, MFMAs)"] if rz else
          ["wait for G, Z + dZ tile to LDS + issue X loads", "dgrad: 64 MFMAs", "wgrad: wait for X + 64 MFMAs",
           "mask / statistics / dX stores"])
-NT = 10 if rz else 12
+NT = 10 if (rz or split) else 12
 ntile = (s[:, :, 2:2 + per * NT:per] > 0).sum(2)                  # tiles stamped per wave (first NT at most)
 life = np.where(s[:, :, 62] > s[:, :, 0], s[:, :, 62] - s[:, :, 0], np.nan)
 print("%s: launch %.1f us (stamped build), grid %d, tiles per wave %d..%d" % (args.kernel, ms * 1e3, grid, ntile.min(), ntile.max()))
