@@ -1,4 +1,7 @@
-T=r04c
+#!/bin/bash
+# Short evidence refresh after a kernel change: PMC bytes of one step (-> profiles/step_traffic.json), both bench lines,
+# kernel traces and step sequences of both configurations.  usage: gpurun -- bash tools/gpu_evidence_short.sh <tag>
+T=${1:-r04d}
 R=$GRAFT_REPO_ROOT
 cd $R
 bash tools/pmc_step.sh ${T} 2>&1 | tail -2
