@@ -492,7 +492,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gnm_tile_rsrc(const float* bas
     // scalar offset too (tools/ubench/soffset_check.hip: a load that leaves the range only through soffset returns 0),
     // so the loads below may carry their row step in soffset; the STORES carry it in the vector offset for another
     // reason (the data-register hazard described at gnm_lin_stream_kernel).
+#ifdef GNM_ABLATE_TILE_TRAFFIC       // tuning builds: every tile descriptor empty -- the kernels' time without tile traffic
+    const unsigned bytes = 0u;
+    (void)rows; (void)ld; (void)width;
+#else
     const unsigned bytes = rows > 0 ? (unsigned)(((rows - 1) * ld + width) * 4) : 0u;
+#endif
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
 
