@@ -25,6 +25,11 @@ CONFIGS = [
     (7, 3, 2, 40, 128, 2, 3, 30, 0.3, True, "sum", "sum"),          # H = 128: two-slice tiles, generic Linear backward
     (8, 2, 2, 7, 64, 2, 1, 400, 0.3, True, "sum", "sum"),           # one true-size graph
     (9, 3, 2, 7, 48, 2, 4, 25, 0.5, True, "average", "average"),    # H = 48: nothing 64-aligned
+    # sparse graphs (below the fill at which batches go to the matrix cores) at H = 32: the CSR gather on 32-float slices
+    # with the fused BatchNorm + ReLU + readout prologue and the fused backward statistics (round 4: gnm_agg_kernel<8, MODE>)
+    (10, 3, 2, 7, 32, 2, 5, 60, 0.03, False, "average", "average"),
+    (11, 4, 2, 7, 32, 3, 6, 70, 0.03, True, "average", "sum"),      # (learn_eps + neighbour "average" would put 0/0 rows
+    (12, 3, 3, 7, 32, 2, 4, 64, 0.035, True, "sum", "sum"),         #  on the isolated nodes such graphs have)
 ]
 
 
